@@ -1,0 +1,141 @@
+/*
+ * tehmm_hip.h -- C ABI of libtehmm_hip.so, the MI355X (gfx950) implementation of teHmm's hot path.
+ *
+ * The library is a drop-in for the seven Cython functions the reference's Python model API calls
+ * (hmm.py:57 `from . import _hmm`, emission.py:19 `from ._emission import ...`) plus fused,
+ * device-resident entry points for the three drivers built on them (BaseHMM.decode,
+ * BaseHMM.score_samples and the Baum-Welch E-step of BaseHMM.fit).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types; every function returns 0 on success or a
+ *     negative TEHMM_ERR_* code (tehmm_last_error() gives the message for the calling thread);
+ *   - all floating point is IEEE fp64, arrays are C-contiguous, little-endian;
+ *   - "host" pointers are ordinary process memory owned by the caller (like the NumPy buffers the
+ *     Cython functions receive); the callee never keeps them after returning;
+ *   - segRatios may be NULL ("None" in the reference);
+ *   - handles are opaque, tied to the HIP device that was current when they were created, and are
+ *     safe to use from one thread at a time.
+ *
+ * Citations are file:line in glennhickey/teHmm.
+ */
+#ifndef TEHMM_HIP_H
+#define TEHMM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TEHMM_OK 0
+#define TEHMM_ERR_ARG (-1)         /* bad argument (NULL, negative size, N out of range ...) */
+#define TEHMM_ERR_HIP (-2)         /* HIP runtime error (no device, out of memory, launch failure) */
+#define TEHMM_ERR_UNSUPPORTED (-3) /* shape outside what the kernels support (see tehmm_max_states) */
+
+/* ---- library / device ---------------------------------------------------------------------- */
+int tehmm_abi_version(void);                 /* bumps when a signature changes */
+const char *tehmm_last_error(void);          /* thread-local message of the last failing call */
+int tehmm_device_count(int *count);          /* hipGetDeviceCount */
+int tehmm_set_device(int device);            /* hipSetDevice; one process per GPU calls this once */
+int tehmm_max_states(void);                  /* largest N the fused kernels accept (128) */
+
+/* ---- array-level entry points: 1:1 replacements of the Cython module functions --------------
+ * Caller owns every buffer (host memory); results are written in place exactly where the Cython
+ * functions write them. */
+
+/* _emission.fastAllLogProbs -> _fastAllLogProbsU8/U16/32 (_emission.pyx:20-144).
+ * obs [T][K], logProbs [K][N][S], outProbs [T][N]; includes the leading-rows quirk (pyx:73-80). */
+int tehmm_emission_u8(int64_t T, int K, int N, int S, const uint8_t *obs, const double *logProbs,
+                      double normalize, const double *segRatios, double *outProbs);
+int tehmm_emission_u16(int64_t T, int K, int N, int S, const uint16_t *obs, const double *logProbs,
+                       double normalize, const double *segRatios, double *outProbs);
+int tehmm_emission_i32(int64_t T, int K, int N, int S, const int32_t *obs, const double *logProbs,
+                       double normalize, const double *segRatios, double *outProbs);
+
+/* _hmm._forward (_hmm.pyx:120-158): fwdlattice [T][N] out. */
+int tehmm_forward(int64_t T, int N, const double *log_startprob, const double *log_transmat,
+                  const double *framelogprob, const double *segRatios, double *fwdlattice);
+
+/* _hmm._backward (_hmm.pyx:160-198): bwdlattice [T][N] out. */
+int tehmm_backward(int64_t T, int N, const double *log_startprob, const double *log_transmat,
+                   const double *framelogprob, const double *segRatios, double *bwdlattice);
+
+/* _hmm._viterbi (_hmm.pyx:201-259): state_sequence int64 [T] out, *logprob out. */
+int tehmm_viterbi(int64_t T, int N, const double *log_startprob, const double *log_transmat,
+                  const double *segRatios, const double *framelogprob, int64_t *state_sequence,
+                  double *logprob);
+
+/* _hmm._log_sum_lneta (_hmm.pyx:62-117): logsum_lneta [N][N] in/out (caller zero-fills it,
+ * hmm.py:557). */
+int tehmm_xi_logsum(int64_t T, int N, const double *fwdlattice, const double *log_transmat,
+                    const double *bwdlattice, const double *framelogprob, double logprob,
+                    const double *segRatios, double *logsum_lneta);
+
+/* _emission.fastAccumulateStats -> _fastAccumulateStatsU8 (_emission.pyx:146-190):
+ * obsStats [K][N][S] += ... in place. */
+int tehmm_accumulate_obs_u8(int64_t T, int K, int N, int S, const uint8_t *obs, double *obsStats,
+                            const double *posteriors, const double *segRatios);
+
+/* ---- fused, device-resident entry points ------------------------------------------------------
+ * A model handle keeps the N x N log-transition matrix, start vector and emission tables on the
+ * device; a batch handle keeps the observation columns (and segment ratios) of many independent
+ * intervals (TrackTables) on the device, plus the result buffers.  One call then runs a whole
+ * driver of the reference over every interval of the batch. */
+typedef struct tehmm_model tehmm_model_t;
+typedef struct tehmm_batch tehmm_batch_t;
+
+/* Model state the reference keeps in MultitrackHmm._log_transmat / _log_startprob (hmm.py:625-666)
+ * and emissionModel.logProbs [K][N][S] + normalizeFac (emission.py:44,58-60).
+ * symbolsPerTrack (may be NULL) = emissionModel.numSymbolsPerTrack: lets the library pack the
+ * table raggedly (symbols 0..symbolsPerTrack[k] of track k); with NULL all S columns are kept. */
+int tehmm_model_create(int N, int K, int S, const double *log_transmat, const double *log_startprob,
+                       const double *logProbs, double normalize, const int32_t *symbolsPerTrack,
+                       tehmm_model_t **out);
+int tehmm_model_destroy(tehmm_model_t *model);
+
+/* Observations of n_intervals TrackTables, concatenated: interval i is rows
+ * offsets[i] .. offsets[i+1]-1 of obs [total][K] (uint8, IntegerTrackTable.data, track.py:555) and
+ * of segRatios [total] (may be NULL).  obs_on_device != 0: obs/segRatios are device pointers on
+ * the current device (the data stays where it is and is repacked by a kernel). */
+int tehmm_batch_create(int n_intervals, const int64_t *offsets, int K, const uint8_t *obs,
+                       const double *segRatios, int obs_on_device, tehmm_batch_t **out);
+int tehmm_batch_destroy(tehmm_batch_t *batch);
+int64_t tehmm_batch_total(const tehmm_batch_t *batch);
+
+/* Flags for tehmm_eval_batch. */
+#define TEHMM_EVAL_VITERBI 1   /* BaseHMM.decode -> _decode_viterbi (basehmm.py:301-330, 361-396) */
+#define TEHMM_EVAL_POSTERIOR 2 /* BaseHMM.score_samples (basehmm.py:238-273) */
+#define TEHMM_EVAL_USE_RATIOS 4 /* the batch's segRatios apply the way the reference applies them:
+                                   decode: transitions only (Q11); score_samples: never (Q12) */
+
+/* Runs decode and/or score_samples over every interval.  Results stay on the device (fetch with
+ * the tehmm_batch_get_* calls); viterbi_logprob / forward_logprob [n_intervals] are host arrays
+ * (may be NULL). */
+int tehmm_eval_batch(tehmm_model_t *model, tehmm_batch_t *batch, int flags,
+                     double *viterbi_logprob, double *forward_logprob);
+
+/* Copy results of the last tehmm_eval_batch to host memory: paths int64 [total] (the concatenated
+ * state sequences), posteriors [total][N]; row range [row0,row1) of the concatenation. */
+int tehmm_batch_get_paths(tehmm_batch_t *batch, int64_t row0, int64_t row1, int64_t *paths);
+int tehmm_batch_get_posteriors(tehmm_batch_t *batch, int64_t row0, int64_t row1, double *post);
+/* Device pointers of the same buffers (valid until the batch is destroyed or re-evaluated). */
+int tehmm_batch_device_ptrs(tehmm_batch_t *batch, void **paths_i64, void **posteriors_f64);
+
+/* Baum-Welch E-step over every interval of the batch (basehmm.py:504-523 with
+ * MultitrackHmm._accumulate_sufficient_statistics, hmm.py:545-574): accumulates INTO the host
+ * arrays start[N], trans[N][N], obsStats[K][N][S] (the caller initialises them, e.g. with
+ * emission.initStats' fudge) and returns the summed forward log-likelihood.  use_ratios: apply
+ * the batch's segRatios everywhere, as fit does for segmented TrackTables. */
+int tehmm_estep_batch(tehmm_model_t *model, tehmm_batch_t *batch, int use_ratios, double *start,
+                      double *trans, double *obsStats, double *logprob_sum);
+
+/* Per-kernel device time of the last fused call on this batch, measured with HIP events on the
+ * streams the kernels ran on.  names[i] is a static string; returns the number of entries
+ * written (<= max_entries). */
+int tehmm_batch_last_timing(tehmm_batch_t *batch, int max_entries, const char **names,
+                            double *milliseconds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEHMM_HIP_H */

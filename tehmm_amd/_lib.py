@@ -1,0 +1,97 @@
+"""ctypes loader of libtehmm_hip.so (the C ABI in include/tehmm_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtehmm_hip.so")
+
+f64p = ctypes.POINTER(ctypes.c_double)
+i64p = ctypes.POINTER(ctypes.c_int64)
+i32p = ctypes.POINTER(ctypes.c_int32)
+u8p = ctypes.POINTER(ctypes.c_uint8)
+vp = ctypes.c_void_p
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_dbl = ctypes.c_double
+
+# every symbol include/tehmm_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "tehmm_abi_version": (c_int, []),
+    "tehmm_last_error": (ctypes.c_char_p, []),
+    "tehmm_device_count": (c_int, [ctypes.POINTER(c_int)]),
+    "tehmm_set_device": (c_int, [c_int]),
+    "tehmm_max_states": (c_int, []),
+    "tehmm_emission_u8": (c_int, [c_i64, c_int, c_int, c_int, vp, f64p, c_dbl, f64p, f64p]),
+    "tehmm_emission_u16": (c_int, [c_i64, c_int, c_int, c_int, vp, f64p, c_dbl, f64p, f64p]),
+    "tehmm_emission_i32": (c_int, [c_i64, c_int, c_int, c_int, vp, f64p, c_dbl, f64p, f64p]),
+    "tehmm_forward": (c_int, [c_i64, c_int, f64p, f64p, f64p, f64p, f64p]),
+    "tehmm_backward": (c_int, [c_i64, c_int, f64p, f64p, f64p, f64p, f64p]),
+    "tehmm_viterbi": (c_int, [c_i64, c_int, f64p, f64p, f64p, f64p, i64p, f64p]),
+    "tehmm_xi_logsum": (c_int, [c_i64, c_int, f64p, f64p, f64p, f64p, c_dbl, f64p, f64p]),
+    "tehmm_accumulate_obs_u8": (c_int, [c_i64, c_int, c_int, c_int, vp, f64p, f64p, f64p]),
+    "tehmm_model_create": (c_int, [c_int, c_int, c_int, f64p, f64p, f64p, c_dbl, i32p,
+                                   ctypes.POINTER(vp)]),
+    "tehmm_model_destroy": (c_int, [vp]),
+    "tehmm_batch_create": (c_int, [c_int, i64p, c_int, vp, vp, c_int, ctypes.POINTER(vp)]),
+    "tehmm_batch_destroy": (c_int, [vp]),
+    "tehmm_batch_total": (c_i64, [vp]),
+    "tehmm_eval_batch": (c_int, [vp, vp, c_int, f64p, f64p]),
+    "tehmm_batch_get_paths": (c_int, [vp, c_i64, c_i64, i64p]),
+    "tehmm_batch_get_posteriors": (c_int, [vp, c_i64, c_i64, f64p]),
+    "tehmm_batch_device_ptrs": (c_int, [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]),
+    "tehmm_estep_batch": (c_int, [vp, vp, c_int, f64p, f64p, f64p, f64p]),
+    "tehmm_batch_last_timing": (c_int, [vp, c_int, ctypes.POINTER(ctypes.c_char_p), f64p]),
+}
+
+EVAL_VITERBI = 1
+EVAL_POSTERIOR = 2
+EVAL_USE_RATIOS = 4
+
+_lib = None
+
+
+class TeHmmHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (no GPU needed just to load it and resolve the symbols)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TeHmmHipError(
+                "%s not found: build it with `python -m tehmm_amd.build` (hipcc, gfx950). "
+                "There is no CPU fallback for the teHmm hot path." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().tehmm_last_error()
+        raise TeHmmHipError("%s failed (%d): %s" % (what or "tehmm call", rc,
+                                                     msg.decode() if msg else "?"))
+
+
+def device_count():
+    n = c_int(0)
+    rc = load().tehmm_device_count(ctypes.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ptr(a, typ):
+    return None if a is None else a.ctypes.data_as(typ)

@@ -1,0 +1,44 @@
+"""Builds libtehmm_hip.so (hipcc, gfx950) in-tree next to the sources.
+
+-ffp-contract=off is required for bit-exact Viterbi (the reference rounds the multiply and the
+add of the segment-ratio term separately; hipcc's default would contract them into an FMA).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libtehmm_hip.so")
+SOURCES = [os.path.join(CSRC, "tehmm_hip.hip")]
+DEPS = SOURCES + [os.path.join(CSRC, "tehmm_kernels.hip.h"),
+                  os.path.join(os.path.dirname(HERE), "include", "tehmm_hip.h")]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > t for d in DEPS if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
+           "-std=c++17", "-Wall", "-Wno-unused-function", "-o", LIB] + SOURCES
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,687 @@
+// tehmm_hip.hip -- host side of libtehmm_hip.so: the C ABI declared in include/tehmm_hip.h.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see tehmm_amd/build.py).
+#include "tehmm_kernels.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/tehmm_hip.h"
+
+using namespace tehmm;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess)                                                                   \
+      return fail(TEHMM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));        \
+  } while (0)
+
+// RAII device buffer
+template <typename T>
+struct DBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DBuf() = default;
+  DBuf(const DBuf &) = delete;
+  DBuf &operator=(const DBuf &) = delete;
+  ~DBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc((void **)&p, count * sizeof(T));
+  }
+  hipError_t upload(const T *h, size_t count) {
+    hipError_t e = alloc(count);
+    if (e != hipSuccess || count == 0) return e;
+    return hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice);
+  }
+};
+
+int grid_for(int64_t work, int block, int cap = 8192) {
+  int64_t g = (work + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+constexpr int kMaxStates = 128;
+
+// Dynamic LDS above the default limit has to be requested per kernel function.
+template <typename F>
+void allow_lds(F *fn, size_t bytes) {
+  (void)hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace
+
+struct tehmm_model {
+  int N = 0, NP = 0, K = 0, S = 0, R = 0;
+  double normalize = 1.0;
+  DBuf<double> lt, A, AT, pi, tab;
+  int rowbase[TEHMM_MAX_TRACKS];
+  int rowcnt[TEHMM_MAX_TRACKS];
+  std::vector<double> h_lt;   // [N][N] host copy (diag etc.)
+};
+
+struct tehmm_batch {
+  int n = 0, K = 0, KP = 0;
+  int64_t total = 0;       // user rows
+  int64_t total_pad = 0;   // internal positions (64-aligned per interval)
+  bool has_ratios = false;
+  std::vector<int64_t> h_off, h_pos0, h_len;
+  std::vector<int> h_order;
+  std::vector<int64_t> h_chunk0;
+  int n_chunks = 0;
+  DBuf<int64_t> d_out0, d_pos0, d_len, d_chunk0;
+  DBuf<int> d_order, d_chunk_iv;
+  DBuf<uint8_t> obs;
+  DBuf<double> ratios;
+  // results / workspace (allocated lazily for the model's N)
+  int N = 0, NP = 0, TBW = 0;
+  DBuf<int64_t> paths;
+  DBuf<double> post;
+  DBuf<uint32_t> tb;
+  DBuf<uint8_t> G, bstate;
+  DBuf<int> last_state;
+  DBuf<double> vit_lp, fwd_lp;
+  DBuf<int64_t> first_good;
+  hipStream_t sV = nullptr, sP = nullptr;
+  hipEvent_t ev[16];
+  int n_ev = 0;
+  std::vector<std::string> tnames;
+  std::vector<std::pair<int, int>> tpairs;
+  std::vector<double> tms;
+};
+
+// All tehmm_* functions below are declared extern "C" in include/tehmm_hip.h.
+
+int tehmm_abi_version(void) { return 1; }
+const char *tehmm_last_error(void) { return g_err.c_str(); }
+int tehmm_max_states(void) { return kMaxStates; }
+
+int tehmm_device_count(int *count) {
+  if (!count) return fail(TEHMM_ERR_ARG, "count is NULL");
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(TEHMM_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  return TEHMM_OK;
+}
+
+int tehmm_set_device(int device) {
+  HIPCHK(hipSetDevice(device));
+  return TEHMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// array-level entry points
+// ------------------------------------------------------------------------------------------
+template <typename ObsT>
+static int emission_impl(int64_t T, int K, int N, int S, const ObsT *obs, const double *logProbs,
+                         double normalize, const double *segRatios, double *outProbs) {
+  if (T < 0 || K <= 0 || N <= 0 || S <= 0 || !obs || !logProbs || !outProbs)
+    return fail(TEHMM_ERR_ARG, "tehmm_emission: bad argument");
+  if (T == 0) return TEHMM_OK;
+  DBuf<ObsT> d_obs;
+  DBuf<double> d_lp, d_r, d_out;
+  DBuf<unsigned long long> d_fg;
+  HIPCHK(d_obs.upload(obs, (size_t)T * K));
+  HIPCHK(d_lp.upload(logProbs, (size_t)K * N * S));
+  if (segRatios) HIPCHK(d_r.upload(segRatios, (size_t)T));
+  HIPCHK(d_out.alloc((size_t)T * N));
+  unsigned long long big = ~0ull;
+  HIPCHK(d_fg.upload(&big, 1));
+  int g = grid_for(T * N, 256);
+  hipLaunchKernelGGL((k_emission<ObsT>), dim3(g), dim3(256), 0, 0, T, K, N, S, d_obs.p, d_lp.p,
+                     normalize, d_r.p, d_out.p, d_fg.p);
+  hipLaunchKernelGGL(k_emission_fix, dim3(g), dim3(256), 0, 0, T, N, d_out.p, d_fg.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(outProbs, d_out.p, (size_t)T * N * sizeof(double), hipMemcpyDeviceToHost));
+  return TEHMM_OK;
+}
+
+int tehmm_emission_u8(int64_t T, int K, int N, int S, const uint8_t *obs, const double *logProbs,
+                      double normalize, const double *segRatios, double *outProbs) {
+  return emission_impl<uint8_t>(T, K, N, S, obs, logProbs, normalize, segRatios, outProbs);
+}
+int tehmm_emission_u16(int64_t T, int K, int N, int S, const uint16_t *obs, const double *logProbs,
+                       double normalize, const double *segRatios, double *outProbs) {
+  return emission_impl<uint16_t>(T, K, N, S, obs, logProbs, normalize, segRatios, outProbs);
+}
+int tehmm_emission_i32(int64_t T, int K, int N, int S, const int32_t *obs, const double *logProbs,
+                       double normalize, const double *segRatios, double *outProbs) {
+  return emission_impl<int32_t>(T, K, N, S, obs, logProbs, normalize, segRatios, outProbs);
+}
+
+int tehmm_forward(int64_t T, int N, const double *pi, const double *lt, const double *frame,
+                  const double *segRatios, double *fwd) {
+  if (T < 0 || N <= 0 || !pi || !lt || !frame || !fwd)
+    return fail(TEHMM_ERR_ARG, "tehmm_forward: bad argument");
+  if (T == 0) return TEHMM_OK;
+  DBuf<double> d_pi, d_lt, d_fr, d_r, d_out;
+  HIPCHK(d_pi.upload(pi, N));
+  HIPCHK(d_lt.upload(lt, (size_t)N * N));
+  HIPCHK(d_fr.upload(frame, (size_t)T * N));
+  if (segRatios) HIPCHK(d_r.upload(segRatios, (size_t)T));
+  HIPCHK(d_out.alloc((size_t)T * N));
+  hipLaunchKernelGGL(k_forward_log, dim3(1), dim3(64), 2 * N * sizeof(double), 0, T, N, d_pi.p,
+                     d_lt.p, d_fr.p, d_r.p, d_out.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(fwd, d_out.p, (size_t)T * N * sizeof(double), hipMemcpyDeviceToHost));
+  return TEHMM_OK;
+}
+
+int tehmm_backward(int64_t T, int N, const double *pi, const double *lt, const double *frame,
+                   const double *segRatios, double *bwd) {
+  (void)pi;
+  if (T < 0 || N <= 0 || !lt || !frame || !bwd)
+    return fail(TEHMM_ERR_ARG, "tehmm_backward: bad argument");
+  if (T == 0) return TEHMM_OK;
+  DBuf<double> d_lt, d_fr, d_r, d_out;
+  HIPCHK(d_lt.upload(lt, (size_t)N * N));
+  HIPCHK(d_fr.upload(frame, (size_t)T * N));
+  if (segRatios) HIPCHK(d_r.upload(segRatios, (size_t)T));
+  HIPCHK(d_out.alloc((size_t)T * N));
+  hipLaunchKernelGGL(k_backward_log, dim3(1), dim3(64), 3 * N * sizeof(double), 0, T, N, d_lt.p,
+                     d_fr.p, d_r.p, d_out.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(bwd, d_out.p, (size_t)T * N * sizeof(double), hipMemcpyDeviceToHost));
+  return TEHMM_OK;
+}
+
+int tehmm_xi_logsum(int64_t T, int N, const double *fwd, const double *lt, const double *bwd,
+                    const double *frame, double logprob, const double *segRatios, double *out) {
+  if (T < 0 || N <= 0 || !fwd || !lt || !bwd || !frame || !out)
+    return fail(TEHMM_ERR_ARG, "tehmm_xi_logsum: bad argument");
+  DBuf<double> d_f, d_lt, d_b, d_fr, d_r, d_out;
+  HIPCHK(d_f.upload(fwd, (size_t)T * N));
+  HIPCHK(d_b.upload(bwd, (size_t)T * N));
+  HIPCHK(d_fr.upload(frame, (size_t)T * N));
+  HIPCHK(d_lt.upload(lt, (size_t)N * N));
+  if (segRatios) HIPCHK(d_r.upload(segRatios, (size_t)T));
+  HIPCHK(d_out.upload(out, (size_t)N * N));
+  hipLaunchKernelGGL(k_xi_logsum, dim3(grid_for((int64_t)N * N, 64)), dim3(64), 0, 0, T, N, d_f.p,
+                     d_lt.p, d_b.p, d_fr.p, logprob, d_r.p, d_out.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, d_out.p, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost));
+  return TEHMM_OK;
+}
+
+int tehmm_accumulate_obs_u8(int64_t T, int K, int N, int S, const uint8_t *obs, double *obsStats,
+                            const double *post, const double *segRatios) {
+  if (T < 0 || K <= 0 || N <= 0 || S <= 0 || !obs || !obsStats || !post)
+    return fail(TEHMM_ERR_ARG, "tehmm_accumulate_obs_u8: bad argument");
+  if (T == 0) return TEHMM_OK;
+  DBuf<uint8_t> d_obs;
+  DBuf<double> d_st, d_p, d_r;
+  HIPCHK(d_obs.upload(obs, (size_t)T * K));
+  HIPCHK(d_st.upload(obsStats, (size_t)K * N * S));
+  HIPCHK(d_p.upload(post, (size_t)T * N));
+  if (segRatios) HIPCHK(d_r.upload(segRatios, (size_t)T));
+  hipLaunchKernelGGL(k_accumulate_obs, dim3(grid_for((int64_t)K * N, 64)), dim3(64), 0, 0, T, K, N,
+                     S, d_obs.p, d_st.p, d_p.p, d_r.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(obsStats, d_st.p, (size_t)K * N * S * sizeof(double), hipMemcpyDeviceToHost));
+  return TEHMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// model / batch handles
+// ------------------------------------------------------------------------------------------
+int tehmm_model_create(int N, int K, int S, const double *lt, const double *pi,
+                       const double *logProbs, double normalize, const int32_t *symbolsPerTrack,
+                       tehmm_model_t **out) {
+  if (!out) return fail(TEHMM_ERR_ARG, "tehmm_model_create: out is NULL");
+  *out = nullptr;
+  if (N <= 0 || K <= 0 || S <= 0 || !lt || !pi || !logProbs)
+    return fail(TEHMM_ERR_ARG, "tehmm_model_create: bad argument");
+  if (N > kMaxStates || K > TEHMM_MAX_TRACKS || S > 256)
+    return fail(TEHMM_ERR_UNSUPPORTED, "tehmm_model_create: N > 128, K > 128 or S > 256");
+  tehmm_model *m = new tehmm_model();
+  m->N = N;
+  m->K = K;
+  m->S = S;
+  m->NP = (N + 1) & ~1;
+  m->normalize = normalize;
+  const int NP = m->NP;
+  std::vector<double> hlt((size_t)N * NP, 0.0), hA((size_t)N * NP, 0.0), hAT((size_t)N * NP, 0.0),
+      hpi(NP, 0.0);
+  for (int i = 0; i < N; ++i) {
+    hpi[i] = pi[i];
+    for (int j = 0; j < N; ++j) {
+      double l = lt[(size_t)i * N + j];
+      hlt[(size_t)i * NP + j] = l;
+      double a = std::exp(l);
+      hA[(size_t)i * NP + j] = a;
+      hAT[(size_t)j * NP + i] = a;
+    }
+  }
+  m->h_lt.assign(lt, lt + (size_t)N * N);
+  int R = 0;
+  for (int k = 0; k < K; ++k) {
+    int cnt = S;
+    if (symbolsPerTrack) {
+      cnt = symbolsPerTrack[k] + 1;
+      if (cnt < 1) cnt = 1;
+      if (cnt > S) cnt = S;
+    }
+    m->rowbase[k] = R;
+    m->rowcnt[k] = cnt;
+    R += cnt;
+  }
+  m->R = R;
+  std::vector<double> htab((size_t)R * NP, 0.0);
+  for (int k = 0; k < K; ++k)
+    for (int s = 0; s < m->rowcnt[k]; ++s)
+      for (int j = 0; j < N; ++j)
+        htab[(size_t)(m->rowbase[k] + s) * NP + j] = logProbs[((size_t)k * N + j) * S + s];
+  hipError_t e = m->lt.upload(hlt.data(), hlt.size());
+  if (e == hipSuccess) e = m->A.upload(hA.data(), hA.size());
+  if (e == hipSuccess) e = m->AT.upload(hAT.data(), hAT.size());
+  if (e == hipSuccess) e = m->pi.upload(hpi.data(), hpi.size());
+  if (e == hipSuccess) e = m->tab.upload(htab.data(), htab.size());
+  if (e != hipSuccess) {
+    delete m;
+    return fail(TEHMM_ERR_HIP, std::string("tehmm_model_create: ") + hipGetErrorString(e));
+  }
+  *out = m;
+  return TEHMM_OK;
+}
+
+int tehmm_model_destroy(tehmm_model_t *model) {
+  delete model;
+  return TEHMM_OK;
+}
+
+int tehmm_batch_create(int n, const int64_t *offsets, int K, const uint8_t *obs,
+                       const double *segRatios, int obs_on_device, tehmm_batch_t **out) {
+  if (!out) return fail(TEHMM_ERR_ARG, "tehmm_batch_create: out is NULL");
+  *out = nullptr;
+  if (n < 0 || !offsets || K <= 0 || K > TEHMM_MAX_TRACKS || (!obs && n > 0 && offsets[n] > 0))
+    return fail(TEHMM_ERR_ARG, "tehmm_batch_create: bad argument");
+  for (int i = 0; i < n; ++i)
+    if (offsets[i + 1] < offsets[i] || offsets[0] != 0)
+      return fail(TEHMM_ERR_ARG, "tehmm_batch_create: offsets must start at 0 and be non-decreasing");
+  tehmm_batch *b = new tehmm_batch();
+  b->n = n;
+  b->K = K;
+  b->KP = (K + 3) & ~3;
+  b->total = n > 0 ? offsets[n] : 0;
+  b->has_ratios = segRatios != nullptr;
+  b->h_off.assign(offsets, offsets + n + 1);
+  b->h_pos0.resize(n + 1);
+  b->h_len.resize(n);
+  b->h_chunk0.resize(n + 1);
+  int64_t pos = 0, ch = 0;
+  for (int i = 0; i < n; ++i) {
+    int64_t T = offsets[i + 1] - offsets[i];
+    b->h_len[i] = T;
+    b->h_pos0[i] = pos;
+    pos += (T + 63) & ~(int64_t)63;
+    b->h_chunk0[i] = ch;
+    ch += T > 1 ? (T - 1 + TEHMM_TB_CHUNK - 1) / TEHMM_TB_CHUNK : 0;
+  }
+  b->h_pos0[n] = pos;
+  b->h_chunk0[n] = ch;
+  b->total_pad = pos;
+  if (ch > 0x7fffffff) {
+    delete b;
+    return fail(TEHMM_ERR_UNSUPPORTED, "tehmm_batch_create: too many traceback chunks");
+  }
+  b->n_chunks = (int)ch;
+  b->h_order.resize(n);
+  std::iota(b->h_order.begin(), b->h_order.end(), 0);
+  std::stable_sort(b->h_order.begin(), b->h_order.end(),
+                   [&](int x, int y) { return b->h_len[x] > b->h_len[y]; });
+  std::vector<int> chunk_iv((size_t)b->n_chunks);
+  for (int i = 0; i < n; ++i)
+    for (int64_t c = b->h_chunk0[i]; c < b->h_chunk0[i + 1]; ++c) chunk_iv[(size_t)c] = i;
+
+  hipError_t e = hipSuccess;
+  auto up = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  up(b->d_out0.upload(b->h_off.data(), n + 1));
+  up(b->d_pos0.upload(b->h_pos0.data(), n + 1));
+  up(b->d_len.upload(b->h_len.data(), n));
+  up(b->d_chunk0.upload(b->h_chunk0.data(), n + 1));
+  up(b->d_order.upload(b->h_order.data(), n));
+  up(b->d_chunk_iv.upload(chunk_iv.data(), chunk_iv.size()));
+  up(b->obs.alloc((size_t)b->total_pad * b->KP + 16));
+  if (segRatios) up(b->ratios.alloc((size_t)b->total_pad + 8));
+  if (e == hipSuccess && b->total_pad > 0) e = hipMemset(b->obs.p, 0, (size_t)b->total_pad * b->KP + 16);
+  if (e == hipSuccess && segRatios && b->total_pad > 0)
+    e = hipMemset(b->ratios.p, 0, ((size_t)b->total_pad + 8) * sizeof(double));
+  DBuf<uint8_t> stage_obs;
+  DBuf<double> stage_r;
+  const uint8_t *src = obs;
+  const double *rsrc = segRatios;
+  if (e == hipSuccess && !obs_on_device && b->total > 0) {
+    up(stage_obs.upload(obs, (size_t)b->total * K));
+    src = stage_obs.p;
+    if (segRatios) {
+      up(stage_r.upload(segRatios, (size_t)b->total));
+      rsrc = stage_r.p;
+    }
+  }
+  if (e == hipSuccess && n > 0 && b->total > 0) {
+    int64_t maxT = b->h_len[b->h_order[0]];
+    dim3 grid(grid_for(maxT * b->KP, 256, 1024), n);
+    // gridDim.y is limited to 65535
+    if (n > 65535) {
+      delete b;
+      return fail(TEHMM_ERR_UNSUPPORTED, "tehmm_batch_create: more than 65535 intervals per batch");
+    }
+    hipLaunchKernelGGL(k_repack_obs, grid, dim3(256), 0, 0, n, b->d_out0.p, b->d_pos0.p, b->d_len.p, K,
+                       b->KP, src, b->obs.p, rsrc, b->ratios.p);
+    up(hipGetLastError());
+    up(hipDeviceSynchronize());
+  }
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->sV, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->sP, hipStreamNonBlocking);
+  for (int i = 0; i < 16 && e == hipSuccess; ++i) {
+    e = hipEventCreate(&b->ev[i]);
+    if (e == hipSuccess) b->n_ev = i + 1;
+  }
+  if (e != hipSuccess) {
+    tehmm_batch_destroy(b);
+    return fail(TEHMM_ERR_HIP, std::string("tehmm_batch_create: ") + hipGetErrorString(e));
+  }
+  *out = b;
+  return TEHMM_OK;
+}
+
+int tehmm_batch_destroy(tehmm_batch_t *b) {
+  if (!b) return TEHMM_OK;
+  for (int i = 0; i < b->n_ev; ++i) (void)hipEventDestroy(b->ev[i]);
+  if (b->sV) (void)hipStreamDestroy(b->sV);
+  if (b->sP) (void)hipStreamDestroy(b->sP);
+  delete b;
+  return TEHMM_OK;
+}
+
+int64_t tehmm_batch_total(const tehmm_batch_t *b) { return b ? b->total : 0; }
+
+static void fill_tabs(const tehmm_model *m, const tehmm_batch *b, IntervalTab &iv, EmisTab &em,
+                      bool emis_ratios) {
+  iv.order = b->d_order.p;
+  iv.pos0 = b->d_pos0.p;
+  iv.len = b->d_len.p;
+  iv.out0 = b->d_out0.p;
+  iv.n = b->n;
+  em.obs32 = (const uint32_t *)b->obs.p;
+  em.tab = m->tab.p;
+  em.ratios = emis_ratios ? b->ratios.p : nullptr;
+  em.normalize = m->normalize;
+  em.K = m->K;
+  em.KPW = b->KP / 4;
+  em.NP = m->NP;
+  std::memcpy(em.rowbase, m->rowbase, sizeof(em.rowbase));
+  std::memcpy(em.rowcnt, m->rowcnt, sizeof(em.rowcnt));
+}
+
+static int ensure_workspace(tehmm_batch *b, const tehmm_model *m, int flags) {
+  if (b->N != m->N) {
+    b->paths.release();
+    b->post.release();
+    b->tb.release();
+    b->G.release();
+    b->N = m->N;
+    b->NP = m->NP;
+    b->TBW = m->NP;
+  }
+  if ((flags & TEHMM_EVAL_VITERBI) && !b->paths.p) {
+    HIPCHK(b->paths.alloc((size_t)b->total + 1));
+    HIPCHK(b->tb.alloc((size_t)(b->total_pad / 4 + 1) * b->TBW));
+    HIPCHK(b->G.alloc((size_t)(b->n_chunks + 1) * b->NP));
+    HIPCHK(b->bstate.alloc((size_t)b->n_chunks + 1));
+    HIPCHK(b->last_state.alloc((size_t)b->n + 1));
+    HIPCHK(b->vit_lp.alloc((size_t)b->n + 1));
+  }
+  if ((flags & TEHMM_EVAL_POSTERIOR) && !b->post.p) {
+    HIPCHK(b->post.alloc((size_t)b->total * m->N + 1));
+    HIPCHK(b->fwd_lp.alloc((size_t)b->n + 1));
+    HIPCHK(b->first_good.alloc((size_t)b->n + 1));
+  }
+  return TEHMM_OK;
+}
+
+template <int SPL>
+static void launch_viterbi(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv,
+                           const EmisTab &em, bool ratio, hipStream_t st) {
+  size_t lds = ((size_t)m->N * m->NP + (TEHMM_PB + 2) * 64 * SPL) * sizeof(double);
+  allow_lds(k_viterbi<SPL, true, false>, lds);
+  allow_lds(k_viterbi<SPL, false, false>, lds);
+  if (ratio)
+    hipLaunchKernelGGL((k_viterbi<SPL, true, false>), dim3(b->n), dim3(64), lds, st, iv, em, m->N, m->NP,
+                       m->lt.p, m->pi.p, b->ratios.p, (const double *)nullptr, b->TBW, b->tb.p,
+                       b->last_state.p, b->vit_lp.p);
+  else
+    hipLaunchKernelGGL((k_viterbi<SPL, false, false>), dim3(b->n), dim3(64), lds, st, iv, em, m->N,
+                       m->NP, m->lt.p, m->pi.p, (const double *)nullptr, (const double *)nullptr,
+                       b->TBW, b->tb.p, b->last_state.p, b->vit_lp.p);
+}
+
+template <int SPL>
+static void launch_posterior(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv,
+                             const EmisTab &em, hipStream_t st, hipEvent_t mid) {
+  size_t ldsF = ((size_t)m->N * m->NP + (TEHMM_PB + 2) * 64 * SPL + TEHMM_PB) * sizeof(double);
+  size_t ldsB = ((size_t)m->N * m->NP + (TEHMM_PB + 2) * 64 * SPL) * sizeof(double);
+  allow_lds(k_forward_lin<SPL, false>, ldsF);
+  allow_lds(k_backward_lin<SPL, false, true>, ldsB);
+  hipLaunchKernelGGL((k_forward_lin<SPL, false>), dim3(b->n), dim3(64), ldsF, st, iv, em, m->N, m->NP,
+                     m->A.p, m->lt.p, m->pi.p, (const double *)nullptr, b->post.p, b->fwd_lp.p,
+                     b->first_good.p);
+  (void)hipEventRecord(mid, st);
+  hipLaunchKernelGGL((k_backward_lin<SPL, false, true>), dim3(b->n), dim3(64), ldsB, st, iv, em, m->N,
+                     m->NP, m->AT.p, m->lt.p, (const double *)nullptr, b->post.p, b->first_good.p);
+}
+
+int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *viterbi_logprob,
+                     double *forward_logprob) {
+  if (!m || !b) return fail(TEHMM_ERR_ARG, "tehmm_eval_batch: NULL handle");
+  if (m->K != b->K) return fail(TEHMM_ERR_ARG, "tehmm_eval_batch: model/batch track count differ");
+  if (!(flags & (TEHMM_EVAL_VITERBI | TEHMM_EVAL_POSTERIOR)))
+    return fail(TEHMM_ERR_ARG, "tehmm_eval_batch: nothing to do");
+  b->tnames.clear();
+  b->tpairs.clear();
+  b->tms.clear();
+  if (b->n == 0 || b->total == 0) return TEHMM_OK;
+  int rc = ensure_workspace(b, m, flags);
+  if (rc) return rc;
+  const bool ratio = (flags & TEHMM_EVAL_USE_RATIOS) && b->has_ratios;
+  IntervalTab iv;
+  EmisTab em;
+  fill_tabs(m, b, iv, em, false);   // decode / score_samples never apply ratios to emissions
+  const int SPL = m->N <= 64 ? 1 : 2;
+  int evi = 0;
+  if (flags & TEHMM_EVAL_VITERBI) {
+    hipStream_t st = b->sV;
+    (void)hipEventRecord(b->ev[evi], st);
+    if (SPL == 1) launch_viterbi<1>(b, m, iv, em, ratio, st);
+    else launch_viterbi<2>(b, m, iv, em, ratio, st);
+    (void)hipEventRecord(b->ev[evi + 1], st);
+    if (b->n_chunks > 0)
+      hipLaunchKernelGGL(k_tb_compose, dim3(b->n_chunks), dim3(64), 0, st, iv, b->d_chunk_iv.p,
+                         b->d_chunk0.p, m->N, m->NP, b->TBW, b->tb.p, b->G.p);
+    hipLaunchKernelGGL(k_tb_scan, dim3(grid_for(b->n, 64)), dim3(64), 0, st, iv, b->d_chunk0.p, m->NP,
+                       b->G.p, b->last_state.p, b->bstate.p, b->paths.p);
+    if (b->n_chunks > 0)
+      hipLaunchKernelGGL(k_tb_fill, dim3(grid_for(b->n_chunks, 64, 1 << 30)), dim3(64), 0, st, iv,
+                         b->n_chunks, b->d_chunk_iv.p, b->d_chunk0.p, b->TBW, b->tb.p, b->bstate.p,
+                         b->paths.p);
+    (void)hipEventRecord(b->ev[evi + 2], st);
+    b->tnames.push_back("viterbi");
+    b->tpairs.push_back({evi, evi + 1});
+    b->tnames.push_back("traceback");
+    b->tpairs.push_back({evi + 1, evi + 2});
+    evi += 3;
+  }
+  if (flags & TEHMM_EVAL_POSTERIOR) {
+    hipStream_t st = b->sP;
+    (void)hipEventRecord(b->ev[evi], st);
+    if (SPL == 1) launch_posterior<1>(b, m, iv, em, st, b->ev[evi + 1]);
+    else launch_posterior<2>(b, m, iv, em, st, b->ev[evi + 1]);
+    (void)hipEventRecord(b->ev[evi + 2], st);
+    b->tnames.push_back("forward");
+    b->tpairs.push_back({evi, evi + 1});
+    b->tnames.push_back("backward_posterior");
+    b->tpairs.push_back({evi + 1, evi + 2});
+    evi += 3;
+  }
+  HIPCHK(hipGetLastError());
+  if (flags & TEHMM_EVAL_VITERBI) HIPCHK(hipStreamSynchronize(b->sV));
+  if (flags & TEHMM_EVAL_POSTERIOR) HIPCHK(hipStreamSynchronize(b->sP));
+  for (auto &pr : b->tpairs) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, b->ev[pr.first], b->ev[pr.second]);
+    b->tms.push_back((double)ms);
+  }
+  if ((flags & TEHMM_EVAL_VITERBI) && viterbi_logprob)
+    HIPCHK(hipMemcpy(viterbi_logprob, b->vit_lp.p, (size_t)b->n * sizeof(double), hipMemcpyDeviceToHost));
+  if ((flags & TEHMM_EVAL_POSTERIOR) && forward_logprob)
+    HIPCHK(hipMemcpy(forward_logprob, b->fwd_lp.p, (size_t)b->n * sizeof(double), hipMemcpyDeviceToHost));
+  return TEHMM_OK;
+}
+
+int tehmm_batch_get_paths(tehmm_batch_t *b, int64_t row0, int64_t row1, int64_t *paths) {
+  if (!b || !paths || row0 < 0 || row1 < row0 || row1 > b->total)
+    return fail(TEHMM_ERR_ARG, "tehmm_batch_get_paths: bad argument");
+  if (!b->paths.p) return fail(TEHMM_ERR_ARG, "tehmm_batch_get_paths: no Viterbi result in this batch");
+  if (row1 > row0)
+    HIPCHK(hipMemcpy(paths, b->paths.p + row0, (size_t)(row1 - row0) * sizeof(int64_t),
+                     hipMemcpyDeviceToHost));
+  return TEHMM_OK;
+}
+
+int tehmm_batch_get_posteriors(tehmm_batch_t *b, int64_t row0, int64_t row1, double *post) {
+  if (!b || !post || row0 < 0 || row1 < row0 || row1 > b->total)
+    return fail(TEHMM_ERR_ARG, "tehmm_batch_get_posteriors: bad argument");
+  if (!b->post.p) return fail(TEHMM_ERR_ARG, "tehmm_batch_get_posteriors: no posterior result in this batch");
+  if (row1 > row0)
+    HIPCHK(hipMemcpy(post, b->post.p + (size_t)row0 * b->N, (size_t)(row1 - row0) * b->N * sizeof(double),
+                     hipMemcpyDeviceToHost));
+  return TEHMM_OK;
+}
+
+int tehmm_batch_device_ptrs(tehmm_batch_t *b, void **paths_i64, void **posteriors_f64) {
+  if (!b) return fail(TEHMM_ERR_ARG, "tehmm_batch_device_ptrs: NULL handle");
+  if (paths_i64) *paths_i64 = b->paths.p;
+  if (posteriors_f64) *posteriors_f64 = b->post.p;
+  return TEHMM_OK;
+}
+
+int tehmm_batch_last_timing(tehmm_batch_t *b, int max_entries, const char **names, double *ms) {
+  if (!b) return 0;
+  int n = (int)std::min<size_t>(b->tms.size(), (size_t)std::max(0, max_entries));
+  for (int i = 0; i < n; ++i) {
+    if (names) names[i] = b->tnames[i].c_str();
+    if (ms) ms[i] = b->tms[i];
+  }
+  return n;
+}
+
+// Array-level Viterbi: one interval, frame input, through the same kernel + traceback.
+int tehmm_viterbi(int64_t T, int N, const double *pi, const double *lt, const double *segRatios,
+                  const double *frame, int64_t *path, double *logprob) {
+  if (T < 0 || N <= 0 || !pi || !lt || !frame || !path || !logprob)
+    return fail(TEHMM_ERR_ARG, "tehmm_viterbi: bad argument");
+  if (N > kMaxStates) return fail(TEHMM_ERR_UNSUPPORTED, "tehmm_viterbi: N > 128");
+  if (T == 0) return TEHMM_OK;
+  const int NP = (N + 1) & ~1;
+  std::vector<double> hlt((size_t)N * NP, 0.0), hpi(NP, 0.0);
+  for (int i = 0; i < N; ++i) {
+    hpi[i] = pi[i];
+    for (int j = 0; j < N; ++j) hlt[(size_t)i * NP + j] = lt[(size_t)i * N + j];
+  }
+  const int64_t Tpad = (T + 63) & ~(int64_t)63;
+  const int64_t nch64 = T > 1 ? (T - 1 + TEHMM_TB_CHUNK - 1) / TEHMM_TB_CHUNK : 0;
+  if (nch64 > 0x7fffffff) return fail(TEHMM_ERR_UNSUPPORTED, "tehmm_viterbi: T too large");
+  const int nch = (int)nch64;
+  int64_t h_off[2] = {0, T}, h_pos0[2] = {0, Tpad}, h_len[1] = {T}, h_chunk0[2] = {0, nch};
+  int h_order[1] = {0};
+  std::vector<int> chunk_iv((size_t)nch, 0);
+  DBuf<double> d_lt, d_pi, d_fr, d_r, d_lp;
+  DBuf<int64_t> d_off, d_pos0, d_len, d_chunk0, d_paths;
+  DBuf<int> d_order, d_chunk_iv, d_last;
+  DBuf<uint32_t> d_tb;
+  DBuf<uint8_t> d_G, d_bs;
+  HIPCHK(d_lt.upload(hlt.data(), hlt.size()));
+  HIPCHK(d_pi.upload(hpi.data(), hpi.size()));
+  HIPCHK(d_fr.upload(frame, (size_t)T * N));
+  if (segRatios) {
+    std::vector<double> r((size_t)Tpad, 0.0);
+    std::copy(segRatios, segRatios + T, r.begin());
+    HIPCHK(d_r.upload(r.data(), r.size()));
+  }
+  HIPCHK(d_off.upload(h_off, 2));
+  HIPCHK(d_pos0.upload(h_pos0, 2));
+  HIPCHK(d_len.upload(h_len, 1));
+  HIPCHK(d_chunk0.upload(h_chunk0, 2));
+  HIPCHK(d_order.upload(h_order, 1));
+  HIPCHK(d_chunk_iv.upload(chunk_iv.data(), chunk_iv.size()));
+  HIPCHK(d_paths.alloc((size_t)T));
+  HIPCHK(d_tb.alloc((size_t)(Tpad / 4 + 1) * NP));
+  HIPCHK(d_G.alloc((size_t)(nch + 1) * NP));
+  HIPCHK(d_bs.alloc((size_t)nch + 1));
+  HIPCHK(d_last.alloc(1));
+  HIPCHK(d_lp.alloc(1));
+  IntervalTab iv;
+  iv.order = d_order.p;
+  iv.pos0 = d_pos0.p;
+  iv.len = d_len.p;
+  iv.out0 = d_off.p;
+  iv.n = 1;
+  EmisTab em;
+  std::memset(&em, 0, sizeof(em));
+  const int SPL = N <= 64 ? 1 : 2;
+  size_t lds = ((size_t)N * NP + (TEHMM_PB + 2) * 64 * SPL) * sizeof(double);
+#define VIT_LAUNCH(S_, R_)                                                                          \
+  allow_lds(k_viterbi<S_, R_, true>, lds);                                                          \
+  hipLaunchKernelGGL((k_viterbi<S_, R_, true>), dim3(1), dim3(64), lds, 0, iv, em, N, NP, d_lt.p,     \
+                     d_pi.p, d_r.p, d_fr.p, NP, d_tb.p, d_last.p, d_lp.p)
+  if (SPL == 1) {
+    if (segRatios) { VIT_LAUNCH(1, true); } else { VIT_LAUNCH(1, false); }
+  } else {
+    if (segRatios) { VIT_LAUNCH(2, true); } else { VIT_LAUNCH(2, false); }
+  }
+#undef VIT_LAUNCH
+  if (nch > 0)
+    hipLaunchKernelGGL(k_tb_compose, dim3(nch), dim3(64), 0, 0, iv, d_chunk_iv.p, d_chunk0.p, N, NP, NP,
+                       d_tb.p, d_G.p);
+  hipLaunchKernelGGL(k_tb_scan, dim3(1), dim3(64), 0, 0, iv, d_chunk0.p, NP, d_G.p, d_last.p, d_bs.p,
+                     d_paths.p);
+  if (nch > 0)
+    hipLaunchKernelGGL(k_tb_fill, dim3(grid_for(nch, 64, 1 << 30)), dim3(64), 0, 0, iv, nch,
+                       d_chunk_iv.p, d_chunk0.p, NP, d_tb.p, d_bs.p, d_paths.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(path, d_paths.p, (size_t)T * sizeof(int64_t), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(logprob, d_lp.p, sizeof(double), hipMemcpyDeviceToHost));
+  return TEHMM_OK;
+}
+
+int tehmm_estep_batch(tehmm_model_t *m, tehmm_batch_t *b, int use_ratios, double *start,
+                      double *trans, double *obsStats, double *logprob_sum) {
+  (void)m; (void)b; (void)use_ratios; (void)start; (void)trans; (void)obsStats; (void)logprob_sum;
+  return fail(TEHMM_ERR_UNSUPPORTED, "tehmm_estep_batch: not built yet");
+}
+

@@ -1,0 +1,768 @@
+// tehmm_kernels.hip.h -- device code of libtehmm_hip.so (gfx950 / CDNA4, wave64).
+//
+// Layout conventions (device side)
+//   * one wavefront owns one interval (TrackTable); lane j (and j+64 when SPL==2) owns state j;
+//   * the N x N transition table lives in LDS as [from][NP] rows so that "lane = to" reads are
+//     conflict-free ds_read_b64 and the previous state vector is an LDS broadcast read;
+//   * observations are repacked to [position][KP] bytes (KP = K rounded up to 4) so that one row
+//     is a wave-uniform (scalar) load; emission tables are packed [row][NP] with one row per
+//     (track, symbol) so that a row read is one coalesced 8*N byte load;
+//   * every interval starts at an internal position base that is a multiple of 64.
+//
+// Arithmetic: fp64 everywhere; the file must be compiled with -ffp-contract=off because the
+// Viterbi recurrence has to reproduce the reference's separate multiply / add roundings
+// (SURVEY Appendix B, Q6).  No MFMA: the recurrences are max-plus / scaled sum-product
+// vector-matrix steps on the VALU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TEHMM_WAVE 64
+#define TEHMM_MAX_TRACKS 128
+#define TEHMM_PB 16          // positions per emission phase (LDS ring depth)
+#define TEHMM_TB_CHUNK 256   // traceback chunk length
+
+namespace tehmm {
+
+struct EmisTab {
+  const uint32_t *obs32;   // [pos][KPW] packed observation rows
+  const double *tab;       // [rows][NP] emission log-prob rows
+  const double *ratios;    // per internal position, may be null (emission ratios)
+  double normalize;
+  int K, KPW, NP;
+  int rowbase[TEHMM_MAX_TRACKS];
+  int rowcnt[TEHMM_MAX_TRACKS];
+};
+
+struct IntervalTab {
+  const int *order;        // launch slot -> interval id (longest first)
+  const int64_t *pos0;     // internal (64-aligned) position base per interval
+  const int64_t *len;      // T per interval
+  const int64_t *out0;     // user-facing concatenated row offset per interval
+  int n;
+};
+
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+// frexp-style exponent of a non-negative double (0 -> -1022)
+__device__ __forceinline__ int exp_of(double a) {
+  return ((__double2hiint(a) >> 20) & 0x7ff) - 1022;
+}
+
+// Emission log-likelihood of one position for the states this lane owns.
+// Same operation order as _emission.pyx:65-72: x = 0; x += table[k][j][obs[k]] (k ascending);
+// x *= normalize; x *= ratio.
+template <int SPL>
+__device__ __forceinline__ void emis_log(const EmisTab &e, int64_t gpos, int lane, int N,
+                                         double (&x)[SPL]) {
+  const uint32_t *row = e.obs32 + gpos * e.KPW;
+#pragma unroll
+  for (int s = 0; s < SPL; ++s) x[s] = 0.0;
+  for (int k = 0; k < e.K; ++k) {
+    uint32_t w = row[k >> 2];
+    int sym = (int)((w >> ((k & 3) * 8)) & 0xffu);
+    sym = min(sym, e.rowcnt[k] - 1);
+    const double *tr = e.tab + (int64_t)(e.rowbase[k] + sym) * e.NP;
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) {
+      int j = lane + TEHMM_WAVE * s;
+      if (j < N) x[s] += tr[j];
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < SPL; ++s) x[s] *= e.normalize;
+  if (e.ratios) {
+    double r = e.ratios[gpos];
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) x[s] *= r;
+  }
+}
+
+// max over the valid states of this wave
+template <int SPL>
+__device__ __forceinline__ double row_max(const double (&x)[SPL], int lane, int N) {
+  double m = -INFINITY;
+#pragma unroll
+  for (int s = 0; s < SPL; ++s)
+    if (lane + TEHMM_WAVE * s < N) m = fmax(m, x[s]);
+  return wave_max_f64(m);
+}
+
+// ------------------------------------------------------------------------------------------
+// Observation repack: user [total][K] bytes -> internal [pos][KP] rows at 64-aligned bases.
+// ------------------------------------------------------------------------------------------
+__global__ void k_repack_obs(int n, const int64_t *out0, const int64_t *pos0, const int64_t *len,
+                             int K, int KP, const uint8_t *src, uint8_t *dst,
+                             const double *rsrc, double *rdst) {
+  int iv = blockIdx.y;
+  if (iv >= n) return;
+  int64_t T = len[iv];
+  const uint8_t *s = src + out0[iv] * K;
+  uint8_t *d = dst + pos0[iv] * KP;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < T * KP;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = idx / KP;
+    int k = (int)(idx - t * KP);
+    d[idx] = k < K ? s[t * K + k] : (uint8_t)0;
+  }
+  if (rsrc) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < T;
+         t += (int64_t)gridDim.x * blockDim.x)
+      rdst[pos0[iv] + t] = rsrc[out0[iv] + t];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Array-level emission (fastAllLogProbs, _emission.pyx:20-144)
+// ------------------------------------------------------------------------------------------
+template <typename ObsT>
+__global__ void k_emission(int64_t T, int K, int N, int S, const ObsT *obs, const double *lp,
+                           double normalize, const double *ratios, double *out,
+                           unsigned long long *first_good) {
+  int64_t total = T * N;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = idx / N;
+    int j = (int)(idx - t * N);
+    double x = 0.0;
+    for (int k = 0; k < K; ++k) {
+      int64_t sym = (int64_t)obs[t * K + k];
+      x += lp[((int64_t)k * N + j) * S + sym];
+    }
+    x *= normalize;
+    if (ratios) x *= ratios[t];
+    out[idx] = x;
+    if (x > -1e20) atomicMin(first_good, (unsigned long long)t);
+  }
+}
+// rows before the first emittable row are zeroed (_emission.pyx:73-80, quirk Q9)
+__global__ void k_emission_fix(int64_t T, int N, double *out, const unsigned long long *first_good) {
+  unsigned long long fg = *first_good;
+  int64_t rows = fg > (unsigned long long)T ? T : (int64_t)fg;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < rows * N;
+       idx += (int64_t)gridDim.x * blockDim.x)
+    out[idx] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Array-level forward / backward in log space, exact reference operation order
+// (_hmm.pyx:120-198).  One wave; lane j owns states j, j+64, ...; any N.
+// LDS: 2*N doubles.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_forward_log(int64_t T, int N, const double *pi,
+                                                    const double *lt, const double *frame,
+                                                    const double *ratios, double *fwd) {
+  extern __shared__ double sm[];
+  double *prev = sm, *next = sm + N;
+  const int lane = threadIdx.x;
+  const bool hasr = ratios != nullptr;
+  {
+    double r0 = hasr ? ratios[0] : 0.0;
+    for (int j = lane; j < N; j += TEHMM_WAVE) {
+      double a = pi[j] + frame[j];
+      if (hasr && r0 > 1.) a += lt[(int64_t)j * N + j] * (r0 - 1.);
+      fwd[j] = a;
+      prev[j] = a;
+    }
+  }
+  __syncthreads();
+  for (int64_t t = 1; t < T; ++t) {
+    double rt = hasr ? ratios[t] : 0.0;
+    bool rr = hasr && rt > 1.;
+    for (int j = lane; j < N; j += TEHMM_WAVE) {
+      double add = rr ? lt[(int64_t)j * N + j] * (rt - 1.) : 0.0;
+      double vmax = -INFINITY;
+      for (int i = 0; i < N; ++i) {
+        double w = prev[i] + lt[(int64_t)i * N + j];
+        if (rr) w += add;
+        if (w > vmax) vmax = w;
+      }
+      double ps = 0.0;
+      for (int i = 0; i < N; ++i) {
+        double w = prev[i] + lt[(int64_t)i * N + j];
+        if (rr) w += add;
+        ps += exp(w - vmax);
+      }
+      double v = log(ps) + vmax + frame[t * N + j];
+      if (v <= -1e200) v = -INFINITY;
+      fwd[t * N + j] = v;
+      next[j] = v;
+    }
+    __syncthreads();
+    double *tmp = prev; prev = next; next = tmp;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_backward_log(int64_t T, int N, const double *lt,
+                                                     const double *frame, const double *ratios,
+                                                     double *bwd) {
+  extern __shared__ double sm[];
+  double *prev = sm, *next = sm + N;   // prev holds frame[t+1][j] + bwd[t+1][j] pieces separately
+  double *fb = sm + 2 * N;             // frame row t+1
+  const int lane = threadIdx.x;
+  const bool hasr = ratios != nullptr;
+  {
+    double v = log(1. / (double)N);
+    for (int j = lane; j < N; j += TEHMM_WAVE) {
+      bwd[(T - 1) * N + j] = v;
+      prev[j] = v;
+    }
+  }
+  __syncthreads();
+  for (int64_t t = T - 2; t >= 0; --t) {
+    double rt = hasr ? ratios[t + 1] : 0.0;
+    bool rr = hasr && rt > 1.;
+    for (int j = lane; j < N; j += TEHMM_WAVE) fb[j] = frame[(t + 1) * N + j];
+    __syncthreads();
+    for (int i = lane; i < N; i += TEHMM_WAVE) {
+      double vmax = -INFINITY;
+      for (int j = 0; j < N; ++j) {
+        double w = lt[(int64_t)i * N + j] + fb[j] + prev[j];
+        if (rr) w += lt[(int64_t)j * N + j] * (rt - 1.);
+        if (w > vmax) vmax = w;
+      }
+      double ps = 0.0;
+      for (int j = 0; j < N; ++j) {
+        double w = lt[(int64_t)i * N + j] + fb[j] + prev[j];
+        if (rr) w += lt[(int64_t)j * N + j] * (rt - 1.);
+        ps += exp(w - vmax);
+      }
+      double v = log(ps) + vmax;
+      if (v <= -1e200) v = -INFINITY;
+      bwd[t * N + i] = v;
+      next[i] = v;
+    }
+    __syncthreads();
+    double *tmp = prev; prev = next; next = tmp;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Array-level xi log-sum (_hmm.pyx:62-117): one thread per (i, j) pair, sequential over t so the
+// two-pass max / sum keeps the reference's accumulation order.
+// ------------------------------------------------------------------------------------------
+__global__ void k_xi_logsum(int64_t T, int N, const double *fwd, const double *lt,
+                            const double *bwd, const double *frame, double logprob,
+                            const double *ratios, double *out) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * N) return;
+  int i = idx / N, j = idx - i * N;
+  const bool hasr = ratios != nullptr;
+  double lij = lt[idx], ljj = lt[(int64_t)j * N + j];
+  double mx = -INFINITY;
+  for (int64_t t = 0; t < T - 1; ++t) {
+    double x = fwd[t * N + i] + lij + frame[(t + 1) * N + j] + bwd[(t + 1) * N + j] - logprob;
+    if (hasr && ratios[t + 1] > 1.) {
+      x += ljj * (ratios[t + 1] - 1.);
+      if (i == j) {
+        double y = fwd[(t + 1) * N + i] + bwd[(t + 1) * N + j] + log(ratios[t + 1] - 1.) - logprob;
+        if (y > mx) mx = y;
+      }
+    }
+    if (x > mx) mx = x;
+  }
+  double acc = out[idx];
+  for (int64_t t = 0; t < T - 1; ++t) {
+    double x = fwd[t * N + i] + lij + frame[(t + 1) * N + j] + bwd[(t + 1) * N + j] - logprob;
+    if (hasr && ratios[t + 1] > 1.) {
+      x += ljj * (ratios[t + 1] - 1.);
+      if (i == j) {
+        double y = fwd[(t + 1) * N + i] + bwd[(t + 1) * N + j] + log(ratios[t + 1] - 1.) - logprob;
+        acc += exp(y - mx);
+      }
+    }
+    acc += exp(x - mx);
+  }
+  out[idx] = log(acc) + mx;
+}
+
+// ------------------------------------------------------------------------------------------
+// Array-level emission statistics (_emission.pyx:165-190): one thread per (track, state) row of
+// obsStats, sequential over t (same accumulation order as the reference, no atomics).
+// ------------------------------------------------------------------------------------------
+__global__ void k_accumulate_obs(int64_t T, int K, int N, int S, const uint8_t *obs,
+                                 double *obsStats, const double *post, const double *ratios) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= K * N) return;
+  int k = idx / N, j = idx - k * N;
+  double *row = obsStats + (int64_t)idx * S;
+  for (int64_t t = 0; t < T; ++t) {
+    double p = post[t * N + j];
+    if (ratios) p *= ratios[t];
+    row[obs[t * K + k]] += p;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Viterbi (fused emission or frame input).  _hmm.pyx:201-259 operation order:
+//   from = 0 : c = (V[t-1][0] + lt[0][to]) + b[t][to]; if ratios: c += lt[to][to]*r[t],
+//              and if to == 0: c -= lt[0][0]                                  (quirk Q4)
+//   from >= 1: c = (V[t-1][from] + lt[from][to]) + b[t][to]; if ratios and r[t] > 1:
+//              c += lt[to][to]*(r[t]-1);  strict '>' keeps the lowest index on ties (Q5).
+// Traceback pointers: one byte per (t, state), four consecutive t packed per dword:
+//   tb[((pos0 + t) >> 2) * TBW + state] byte (t & 3).
+// LDS: lt [N][NP] | ring [PB][64*SPL] | v [2][64*SPL]
+// ------------------------------------------------------------------------------------------
+template <int SPL, bool RATIO, bool FRAME>
+__global__ __launch_bounds__(64) void k_viterbi(IntervalTab iv, EmisTab em, int N, int NP,
+                                                const double *g_lt, const double *g_pi,
+                                                const double *tratios, const double *frame,
+                                                int TBW, uint32_t *tb, int *last_state,
+                                                double *logprob) {
+  extern __shared__ double sm[];
+  constexpr int W = TEHMM_WAVE * SPL;
+  double *LT = sm;
+  double *ring = LT + (size_t)N * NP;
+  double *vb = ring + TEHMM_PB * W;
+  const int lane = threadIdx.x;
+  const int id = iv.order[blockIdx.x];
+  const int64_t T = iv.len[id];
+  const int64_t p0 = iv.pos0[id];
+  if (T <= 0) return;
+
+  for (int idx = lane; idx < N * NP; idx += TEHMM_WAVE) LT[idx] = g_lt[idx];
+  double ltd[SPL];
+#pragma unroll
+  for (int s = 0; s < SPL; ++s) {
+    int j = lane + TEHMM_WAVE * s;
+    ltd[s] = j < N ? g_lt[(size_t)j * NP + j] : 0.0;
+  }
+  const double lt00 = g_lt[0];
+  __syncthreads();
+
+  bool seen = false;
+  int cur = 0;
+  uint32_t tbw[SPL];
+#pragma unroll
+  for (int s = 0; s < SPL; ++s) tbw[s] = 0;
+
+  for (int64_t t0 = 0; t0 < T; t0 += TEHMM_PB) {
+    const int np = (int)min((int64_t)TEHMM_PB, T - t0);
+    // ---- phase 1: emission rows of this block into the LDS ring (independent of the chain)
+    for (int p = 0; p < np; ++p) {
+      double x[SPL];
+      if (FRAME) {
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) {
+          int j = lane + TEHMM_WAVE * s;
+          x[s] = j < N ? frame[(t0 + p) * N + j] : -INFINITY;
+        }
+      } else {
+        emis_log<SPL>(em, p0 + t0 + p, lane, N, x);
+        if (!seen) {   // _emission.pyx:73-80: only rows before the first emittable row
+          double m = row_max<SPL>(x, lane, N);
+          if (m > -1e20) seen = true;
+          else {
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) x[s] = 0.0;
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < SPL; ++s) ring[p * W + lane + TEHMM_WAVE * s] = x[s];
+    }
+    __syncthreads();
+    // ---- phase 2: the sequential max-plus chain
+    for (int p = 0; p < np; ++p) {
+      const int64_t t = t0 + p;
+      double b[SPL];
+#pragma unroll
+      for (int s = 0; s < SPL; ++s) b[s] = ring[p * W + lane + TEHMM_WAVE * s];
+      double r = 0.0;
+      if (RATIO) r = tratios[p0 + t];
+      double *vprev = vb + cur * W;
+      double *vnext = vb + (cur ^ 1) * W;
+      if (t == 0) {
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) {
+          int j = lane + TEHMM_WAVE * s;
+          if (j < N) {
+            double v = g_pi[j] + b[s];
+            if (RATIO && r > 1.) v += ltd[s] * (r - 1.);
+            vnext[j] = v;
+          }
+        }
+      } else {
+        const bool rg = RATIO && r > 1.;
+        const double rm1 = r - 1.;
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) {
+          int j = lane + TEHMM_WAVE * s;
+          int jj = j < N ? j : 0;
+          double best = (vprev[0] + LT[jj]) + b[s];
+          if (RATIO) {
+            best += ltd[s] * r;
+            if (j == 0) best -= lt00;
+          }
+          int arg = 0;
+          const double addr = ltd[s] * rm1;
+          if (rg) {
+#pragma unroll 4
+            for (int from = 1; from < N; ++from) {
+              double c = (vprev[from] + LT[from * NP + jj]) + b[s];
+              c += addr;
+              if (c > best) { best = c; arg = from; }
+            }
+          } else {
+#pragma unroll 4
+            for (int from = 1; from < N; ++from) {
+              double c = (vprev[from] + LT[from * NP + jj]) + b[s];
+              if (c > best) { best = c; arg = from; }
+            }
+          }
+          if (j < N) vnext[j] = best;
+          tbw[s] |= (uint32_t)arg << ((t & 3) * 8);
+        }
+      }
+      if ((t & 3) == 3 || t == T - 1) {
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) {
+          int j = lane + TEHMM_WAVE * s;
+          if (j < TBW) tb[((p0 + t) >> 2) * TBW + j] = tbw[s];
+          tbw[s] = 0;
+        }
+      }
+      cur ^= 1;
+      __syncthreads();
+    }
+  }
+  // np.argmax over V[T-1] (first maximum; a NaN wins as soon as it is met)
+  if (lane == 0) {
+    const double *v = vb + cur * W;
+    int last = 0;
+    double m = v[0];
+    if (m == m) {
+      for (int j = 1; j < N; ++j) {
+        double x = v[j];
+        if (x != x) { last = j; break; }
+        if (x > m) { m = x; last = j; }
+      }
+    }
+    last_state[id] = last;
+    logprob[id] = v[last];
+  }
+}
+
+__device__ __forceinline__ int tb_get(const uint32_t *tb, int TBW, int64_t gpos, int s) {
+  return (int)((tb[(gpos >> 2) * TBW + s] >> ((gpos & 3) * 8)) & 0xffu);
+}
+
+// Chunk c of an interval covers pointers t in (lo, hi], lo = c*C, hi = min((c+1)*C, T-1), and maps
+// the state at hi to the state at lo.  compose: G[chunk][s_hi] = s_lo for every s_hi.
+__global__ __launch_bounds__(64) void k_tb_compose(IntervalTab iv, const int *chunk_iv,
+                                                   const int64_t *chunk0, int N, int NP, int TBW,
+                                                   const uint32_t *tb, uint8_t *G) {
+  const int c = blockIdx.x;
+  const int id = chunk_iv[c];
+  const int64_t T = iv.len[id], p0 = iv.pos0[id];
+  const int64_t cl = c - chunk0[id];
+  const int64_t lo = cl * TEHMM_TB_CHUNK;
+  const int64_t hi = min(lo + TEHMM_TB_CHUNK, T - 1);
+  for (int s0 = threadIdx.x; s0 < N; s0 += TEHMM_WAVE) {
+    int s = s0;
+    for (int64_t t = hi; t > lo; --t) s = tb_get(tb, TBW, p0 + t, s);
+    G[(int64_t)c * NP + s0] = (uint8_t)s;
+  }
+}
+// scan: sequential over the chunks of one interval (T/C dependent byte lookups)
+__global__ void k_tb_scan(IntervalTab iv, const int64_t *chunk0, int NP, const uint8_t *G,
+                          const int *last_state, uint8_t *bstate, int64_t *paths) {
+  int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= iv.n) return;
+  int64_t T = iv.len[id];
+  if (T <= 0) return;
+  int s = last_state[id];
+  int64_t c0 = chunk0[id], nc = chunk0[id + 1] - c0;
+  if (nc == 0) { paths[iv.out0[id]] = s; return; }
+  for (int64_t c = nc - 1; c >= 0; --c) {
+    bstate[c0 + c] = (uint8_t)s;
+    s = G[(c0 + c) * NP + s];
+  }
+}
+// fill: one thread per chunk walks its pointers and writes the int64 path
+__global__ void k_tb_fill(IntervalTab iv, int n_chunks, const int *chunk_iv, const int64_t *chunk0,
+                          int TBW, const uint32_t *tb, const uint8_t *bstate, int64_t *paths) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_chunks) return;
+  const int id = chunk_iv[c];
+  const int64_t T = iv.len[id], p0 = iv.pos0[id];
+  const int64_t cl = c - chunk0[id];
+  const int64_t lo = cl * TEHMM_TB_CHUNK;
+  const int64_t hi = min(lo + TEHMM_TB_CHUNK, T - 1);
+  int64_t *out = paths + iv.out0[id];
+  int s = bstate[c];
+  out[hi] = s;
+  for (int64_t t = hi; t > lo; --t) {
+    s = tb_get(tb, TBW, p0 + t, s);
+    out[t - 1] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward pass in the scaled linear domain (sum-product form of _hmm.pyx:120-158).
+//   a_t[j] = bh_t[j] * sum_i a_{t-1}[i] * A[i][j],  bh_t = exp(b_t - max_j b_t)
+// Scaling is by exact powers of two: a_t is multiplied by 2^-e where e is the binary exponent of
+// max_j a_{t-1} (known before step t ends, so it is off the critical path); the exponents and the
+// emission shifts are summed and give log P(obs) = log(sum_j a_{T-1}) + ln2*E + M.
+// The scaled a_t rows are written to the posterior buffer; the backward kernel turns them into
+// posteriors in place.  TRATIO: transition segment-ratio factor exp(lt[j][j]*(r_t-1)) for r_t > 1.
+// LDS: A [N][NP] | ring [PB][W] | v [2][W] | ms [PB]
+// ------------------------------------------------------------------------------------------
+template <int SPL, bool TRATIO>
+__global__ __launch_bounds__(64) void k_forward_lin(IntervalTab iv, EmisTab em, int N, int NP,
+                                                    const double *g_A, const double *g_lt,
+                                                    const double *g_pi, const double *tratios,
+                                                    double *post, double *fwd_logprob,
+                                                    int64_t *first_good) {
+  extern __shared__ double sm[];
+  constexpr int W = TEHMM_WAVE * SPL;
+  double *A = sm;
+  double *ring = A + (size_t)N * NP;
+  double *vb = ring + TEHMM_PB * W;
+  double *ms = vb + 2 * W;
+  const int lane = threadIdx.x;
+  const int id = iv.order[blockIdx.x];
+  const int64_t T = iv.len[id];
+  const int64_t p0 = iv.pos0[id];
+  if (T <= 0) return;
+  double *out = post + iv.out0[id] * N;
+
+  for (int idx = lane; idx < N * NP; idx += TEHMM_WAVE) A[idx] = g_A[idx];
+  double ltd[SPL];
+#pragma unroll
+  for (int s = 0; s < SPL; ++s) {
+    int j = lane + TEHMM_WAVE * s;
+    ltd[s] = j < N ? g_lt[(size_t)j * NP + j] : 0.0;
+  }
+  __syncthreads();
+
+  bool seen = false;
+  int64_t fg = T;
+  int cur = 0;
+  int eprev = 0;
+  double Ecum = 0.0, Mcum = 0.0;
+  double a[SPL];
+
+  for (int64_t t0 = 0; t0 < T; t0 += TEHMM_PB) {
+    const int np = (int)min((int64_t)TEHMM_PB, T - t0);
+    for (int p = 0; p < np; ++p) {
+      double x[SPL];
+      emis_log<SPL>(em, p0 + t0 + p, lane, N, x);
+      if (!seen) {
+        double m0 = row_max<SPL>(x, lane, N);
+        if (m0 > -1e20) { seen = true; fg = t0 + p; }
+        else {
+#pragma unroll
+          for (int s = 0; s < SPL; ++s) x[s] = 0.0;
+        }
+      }
+      if (TRATIO) {
+        double r = tratios[p0 + t0 + p];
+        if (r > 1.) {
+#pragma unroll
+          for (int s = 0; s < SPL; ++s) x[s] += ltd[s] * (r - 1.);
+        }
+      }
+      double m = row_max<SPL>(x, lane, N);
+#pragma unroll
+      for (int s = 0; s < SPL; ++s) ring[p * W + lane + TEHMM_WAVE * s] = exp(x[s] - m);
+      if (lane == 0) ms[p] = m;
+    }
+    __syncthreads();
+    for (int p = 0; p < np; ++p) {
+      const int64_t t = t0 + p;
+      double *vprev = vb + cur * W;
+      double *vnext = vb + (cur ^ 1) * W;
+      Mcum += ms[p];
+      if (t == 0) {
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) {
+          int j = lane + TEHMM_WAVE * s;
+          a[s] = j < N ? exp(g_pi[j]) * ring[p * W + j] : 0.0;
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) {
+          int j = lane + TEHMM_WAVE * s;
+          int jj = j < N ? j : 0;
+          double acc0 = 0.0, acc1 = 0.0;
+          int i = 0;
+          for (; i + 1 < N; i += 2) {
+            acc0 = fma(vprev[i], A[i * NP + jj], acc0);
+            acc1 = fma(vprev[i + 1], A[(i + 1) * NP + jj], acc1);
+          }
+          if (i < N) acc0 = fma(vprev[i], A[i * NP + jj], acc0);
+          double v = (acc0 + acc1) * ring[p * W + lane + TEHMM_WAVE * s];
+          a[s] = j < N ? ldexp(v, -eprev) : 0.0;
+        }
+        Ecum += (double)eprev;
+      }
+      int e = -1022;
+#pragma unroll
+      for (int s = 0; s < SPL; ++s) {
+        int j = lane + TEHMM_WAVE * s;
+        if (j < N) {
+          vnext[j] = a[s];
+          out[t * N + j] = a[s];
+          e = max(e, exp_of(a[s]));
+        }
+      }
+      eprev = wave_max_i32(e);
+      cur ^= 1;
+      __syncthreads();
+    }
+  }
+  double tot = 0.0;
+#pragma unroll
+  for (int s = 0; s < SPL; ++s) tot += a[s];
+  tot = wave_sum_f64(tot);
+  if (lane == 0) {
+    fwd_logprob[id] = log(tot) + Ecum * 0.6931471805599453 + Mcum;
+    first_good[id] = fg;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward pass in the scaled linear domain + posterior (sum-product form of _hmm.pyx:160-198
+// and basehmm.py:265-272 / 516-517):
+//   w_{t+1}[j] = bh_{t+1}[j] * beta_{t+1}[j];  beta_t[i] = sum_j A[i][j] * w_{t+1}[j]
+//   post_t = normalise(a_t * beta_t);  EPS: += float32 eps, renormalise (score_samples only).
+// AT is A transposed ([to][NP] rows indexed by from-lane).  The terminal beta is a constant
+// (log(1/N) in the reference), which the per-row normalisation removes.
+// LDS: AT [N][NP] | ring [PB][W] | w [2][W]
+// ------------------------------------------------------------------------------------------
+template <int SPL, bool TRATIO, bool EPS>
+__global__ __launch_bounds__(64) void k_backward_lin(IntervalTab iv, EmisTab em, int N, int NP,
+                                                     const double *g_AT, const double *g_lt,
+                                                     const double *tratios, double *post,
+                                                     const int64_t *first_good) {
+  extern __shared__ double sm[];
+  constexpr int W = TEHMM_WAVE * SPL;
+  double *AT = sm;
+  double *ring = AT + (size_t)N * NP;
+  double *wb = ring + TEHMM_PB * W;
+  const int lane = threadIdx.x;
+  const int id = iv.order[blockIdx.x];
+  const int64_t T = iv.len[id];
+  const int64_t p0 = iv.pos0[id];
+  if (T <= 0) return;
+  double *out = post + iv.out0[id] * N;
+  const int64_t fg = first_good[id];
+
+  for (int idx = lane; idx < N * NP; idx += TEHMM_WAVE) AT[idx] = g_AT[idx];
+  double ltd[SPL];
+#pragma unroll
+  for (int s = 0; s < SPL; ++s) {
+    int j = lane + TEHMM_WAVE * s;
+    ltd[s] = j < N ? g_lt[(size_t)j * NP + j] : 0.0;
+  }
+  __syncthreads();
+
+  const double eps = 1.1920928955078125e-07;
+  const double epsden = 1.0 + (double)N * eps;
+  double beta[SPL];
+  int cur = 0;
+  int eprev = 0;
+
+  // position T-1: beta = 1
+  {
+    double g[SPL], tot = 0.0;
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) {
+      int j = lane + TEHMM_WAVE * s;
+      beta[s] = j < N ? 1.0 : 0.0;
+      g[s] = j < N ? out[(T - 1) * N + j] : 0.0;
+      tot += g[s];
+    }
+    tot = wave_sum_f64(tot);
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) {
+      int j = lane + TEHMM_WAVE * s;
+      double pr = g[s] / tot;
+      if (EPS) pr = (pr + eps) / epsden;
+      if (j < N) out[(T - 1) * N + j] = pr;
+    }
+    eprev = 1;   // exponent of 1.0 in the frexp convention
+  }
+
+  // blocks of positions t = T-2 ... 0, each step needs bh'[t+1]
+  for (int64_t thi = T - 2; thi >= 0; thi -= TEHMM_PB) {
+    const int np = (int)min((int64_t)TEHMM_PB, thi + 1);
+    for (int p = 0; p < np; ++p) {   // ring[p] <- bh'[(thi - p) + 1]
+      const int64_t u = thi - p + 1;
+      double x[SPL];
+      emis_log<SPL>(em, p0 + u, lane, N, x);
+      if (u < fg) {
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) x[s] = 0.0;
+      }
+      if (TRATIO) {
+        double r = tratios[p0 + u];
+        if (r > 1.) {
+#pragma unroll
+          for (int s = 0; s < SPL; ++s) x[s] += ltd[s] * (r - 1.);
+        }
+      }
+      double m = row_max<SPL>(x, lane, N);
+#pragma unroll
+      for (int s = 0; s < SPL; ++s) ring[p * W + lane + TEHMM_WAVE * s] = exp(x[s] - m);
+    }
+    __syncthreads();
+    for (int p = 0; p < np; ++p) {
+      const int64_t t = thi - p;
+      double *wv = wb + cur * W;
+      double av[SPL];
+#pragma unroll
+      for (int s = 0; s < SPL; ++s) {
+        int j = lane + TEHMM_WAVE * s;
+        av[s] = j < N ? out[t * N + j] : 0.0;          // scaled alpha row (independent load)
+        if (j < N) wv[j] = ring[p * W + j] * beta[s];
+      }
+      __syncthreads();
+      int e = -1022;
+      double g[SPL], tot = 0.0;
+#pragma unroll
+      for (int s = 0; s < SPL; ++s) {
+        int i = lane + TEHMM_WAVE * s;
+        int ii = i < N ? i : 0;
+        double acc0 = 0.0, acc1 = 0.0;
+        int j = 0;
+        for (; j + 1 < N; j += 2) {
+          acc0 = fma(AT[j * NP + ii], wv[j], acc0);
+          acc1 = fma(AT[(j + 1) * NP + ii], wv[j + 1], acc1);
+        }
+        if (j < N) acc0 = fma(AT[j * NP + ii], wv[j], acc0);
+        beta[s] = i < N ? ldexp(acc0 + acc1, -eprev) : 0.0;
+        e = max(e, exp_of(beta[s]));
+        g[s] = av[s] * beta[s];
+        tot += g[s];
+      }
+      eprev = wave_max_i32(e);
+      tot = wave_sum_f64(tot);
+#pragma unroll
+      for (int s = 0; s < SPL; ++s) {
+        int i = lane + TEHMM_WAVE * s;
+        double pr = g[s] / tot;
+        if (EPS) pr = (pr + eps) / epsden;
+        if (i < N) out[t * N + i] = pr;
+      }
+      cur ^= 1;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace tehmm

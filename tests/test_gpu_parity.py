@@ -1,0 +1,163 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): the HIP path, called through the C ABI,
+against the CPU oracle and the reference's golden vectors.
+
+Bars: Viterbi paths / log-probs and emission frames bit-exact; lattices, posteriors and
+log-likelihoods within 1e-6 relative (BASELINE.json north_star), in practice far tighter."""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_array_equal
+
+from conftest import golden_names, load_golden, ratios_of
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from tehmm_amd import _lib
+    _lib.load()
+    assert _lib.device_count() >= 1, "no HIP device visible"
+    return _lib
+
+
+@pytest.mark.parametrize("name", golden_names("kern_"))
+def test_array_level_vs_golden(hip, name):
+    from tehmm_amd import _emission, _hmm
+    from oracle import oracle
+    g = load_golden(name)
+    r = ratios_of(g)
+    rows = g["rows"]
+    T, K = g["obs"].shape
+    N = g["lt"].shape[0]
+    frame = np.zeros((T, N))
+    _emission.fastAllLogProbs(g["obs"], g["log_probs"], frame, 1.0, r)
+    assert_array_equal(frame[rows], g["frame_rows"])
+    assert_array_equal(frame, oracle.emission(g["obs"], g["log_probs"], 1.0, r))
+    frame_n = np.zeros((T, N))
+    _emission.fastAllLogProbs(g["obs"], g["log_probs"], frame_n, 3.0 / K, r)
+    assert_array_equal(frame_n[rows], g["frame_norm_rows"])
+    fwd = np.zeros((T, N))
+    _hmm._forward(T, N, g["pi"], g["lt"], frame, r, fwd)
+    assert_allclose(fwd[rows], g["fwd_rows"], rtol=1e-9)
+    bwd = np.zeros((T, N))
+    _hmm._backward(T, N, g["pi"], g["lt"], frame, r, bwd)
+    assert_allclose(bwd[rows], g["bwd_rows"], rtol=1e-9)
+    path, lp = _hmm._viterbi(T, N, g["pi"], g["lt"], r, frame)
+    assert path.dtype == np.int64
+    assert_array_equal(path, g["vit_path"].astype(np.int64))
+    assert lp == g["vit_logprob"]
+    xi = np.zeros((N, N))
+    _hmm._log_sum_lneta(T, N, fwd, g["lt"], bwd, frame, float(g["fwd_logprob"]), r, xi)
+    assert_allclose(xi, g["xi_logsum"], rtol=1e-8, atol=1e-8)
+    post_fit = oracle.posteriors(fwd, bwd, 0)
+    stats = np.zeros_like(g["obs_stats"])
+    _emission.fastAccumulateStats(g["obs"], stats, post_fit, r)
+    assert_allclose(stats, g["obs_stats"], rtol=1e-8, atol=1e-300)
+
+
+def test_emission_dtypes_and_quirk(hip):
+    from tehmm_amd import _emission
+    from oracle import oracle
+    g = load_golden("quirk_q9_leading_rows")
+    for dt in (np.uint8, np.uint16, np.int32):
+        obs = g["obs"].astype(dt)
+        out = np.zeros_like(g["frame"])
+        _emission.fastAllLogProbs(obs, g["log_probs"], out, 1.0, None)
+        assert_array_equal(out, g["frame"])
+        assert_array_equal(out, oracle.emission(obs, g["log_probs"]))
+
+
+def _eval(model_args, obs, offs, ratios=None, use_ratios=True):
+    from tehmm_amd.engine import HipBatch, HipModel
+    hm = HipModel(*model_args)
+    hb = HipBatch(obs, offs, ratios)
+    res = hm.eval(hb, viterbi=True, posterior=True, use_ratios=use_ratios)
+    return res, hb.paths(), hb.posteriors(), hb
+
+
+@pytest.mark.parametrize("name", golden_names("kern_"))
+def test_fused_eval_vs_golden(hip, name):
+    """decode + score_samples fused on the device vs the reference drivers' semantics:
+    emission without ratios; Viterbi transitions with ratios; posteriors without."""
+    from oracle import oracle
+    g = load_golden(name)
+    r = ratios_of(g)
+    T = g["obs"].shape[0]
+    offs = np.asarray([0, T], dtype=np.int64)
+    res, paths, post, _ = _eval((g["lt"], g["pi"], g["log_probs"]), g["obs"], offs, r)
+    lp_o, path_o = oracle.decode(g["obs"], g["log_probs"], g["pi"], g["lt"], 1.0, r)
+    assert_array_equal(paths, path_o)
+    assert res["viterbi_logprob"][0] == lp_o
+    flp_o, post_o = oracle.score_samples(g["obs"], g["log_probs"], g["pi"], g["lt"])
+    assert_allclose(res["forward_logprob"][0], flp_o, rtol=RTOL)
+    assert_allclose(post, post_o, rtol=RTOL, atol=1e-15)
+    if r is None:
+        # same numbers as the reference itself produced
+        assert_array_equal(paths, g["vit_path"].astype(np.int64))
+        assert res["viterbi_logprob"][0] == g["vit_logprob"]
+        assert_allclose(res["forward_logprob"][0], g["fwd_logprob"], rtol=RTOL)
+        assert_allclose(post[g["rows"]], g["post_eval_rows"], rtol=RTOL, atol=1e-15)
+
+
+def test_fused_known_answers(hip):
+    g = load_golden("wikipedia")
+    offs = np.asarray([0, 3], dtype=np.int64)
+    res, paths, post, _ = _eval((g["lt"], g["pi"], g["log_probs"]), g["obs"], offs)
+    assert_array_equal(paths, [1, 0, 0])                          # hmmTest.py:59
+    assert abs(np.exp(res["viterbi_logprob"][0]) - 0.01344) < 1e-9    # hmmTest.py:58
+    assert_allclose(post, g["post"], rtol=RTOL)
+    res, paths, _, _ = _eval((g["lt"], g["pi"], g["log_probs4"]), g["obs4"], offs)
+    assert_array_equal(paths, [1, 0, 0])
+    assert res["viterbi_logprob"][0] == g["vit_logprob4"]
+
+
+def test_fused_quirks(hip):
+    g = load_golden("quirk_q1_zero_transitions")
+    T = g["obs"].shape[0]
+    offs = np.asarray([0, T], dtype=np.int64)
+    res, paths, post, _ = _eval((g["lt"], g["pi"], g["log_probs"]), g["obs"], offs)
+    assert_array_equal(paths, g["vit_path"])
+    assert res["viterbi_logprob"][0] == g["vit_logprob"]
+    assert_allclose(post, g["post"], rtol=RTOL, atol=1e-15)
+    assert_allclose(res["forward_logprob"][0], g["fwd_logprob"], rtol=RTOL)
+    g = load_golden("quirk_ties")
+    T = g["obs"].shape[0]
+    offs = np.asarray([0, T], dtype=np.int64)
+    res, paths, _, _ = _eval((g["lt"], g["pi"], g["log_probs"]), g["obs"], offs)
+    assert_array_equal(paths, g["vit_path"])
+    assert res["viterbi_logprob"][0] == g["vit_logprob"]
+    res, paths, _, _ = _eval((g["lt"], g["pi"], g["log_probs"]), g["obs"], offs, g["ratios"])
+    assert_array_equal(paths, g["vit_path_r"])
+    assert res["viterbi_logprob"][0] == g["vit_logprob_r"]
+    g = load_golden("driver_asymmetry")
+    T = g["obs"].shape[0]
+    offs = np.asarray([0, T], dtype=np.int64)
+    res, paths, post, _ = _eval((g["lt"], g["pi"], g["log_probs"]), g["obs"], offs, g["ratios"])
+    assert_array_equal(paths, g["decode_path"])
+    assert res["viterbi_logprob"][0] == g["decode_logprob"]
+    assert_allclose(post, g["score_post"], rtol=RTOL, atol=1e-15)
+
+
+@pytest.mark.parametrize("N,with_ratio", [(35, 0), (35, 1), (100, 0), (5, 1), (64, 0), (65, 1)])
+def test_fused_batch_ragged(hip, N, with_ratio):
+    """Many intervals of ragged lengths (including 1, 2, 3, 4, 5, 63..65, 255..258) in one batch."""
+    from tehmm_amd import synth
+    from oracle import oracle
+    model = synth.make_model(N, seed=N + with_ratio, sparse=0.3 if N == 35 else 0.0)
+    lens = [1, 2, 3, 4, 5, 17, 63, 64, 65, 255, 256, 257, 258, 1000, 1, 513, 31]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = synth.sample_obs(model, int(offs[-1]), seed=5, missing=0.03)
+    ratios = synth.random_ratios(int(offs[-1]), seed=9) if with_ratio else None
+    res, paths, post, hb = _eval((model.log_transmat, model.log_startprob, model.log_probs, 1.0,
+                                  model.symbols_per_track), obs, offs, ratios)
+    p_o, vlp_o, flp_o, post_o = oracle.eval_batch(obs, offs, model.log_probs, model.log_startprob,
+                                                  model.log_transmat, 1.0, ratios, n_threads=4)
+    assert_array_equal(paths, p_o)
+    assert_array_equal(res["viterbi_logprob"], vlp_o)
+    assert_allclose(res["forward_logprob"], flp_o, rtol=RTOL)
+    assert_allclose(post, post_o, rtol=RTOL, atol=1e-15)
+    assert_allclose(post.sum(axis=1), 1.0, rtol=1e-9)
+    t = hb.timing()
+    assert set(t) == {"viterbi", "traceback", "forward", "backward_posterior"}
