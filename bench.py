@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Headline benchmark: genome positions/sec for Viterbi + posterior (teHmmEval's hot path),
+35 states x 10 tracks, on N MI355X (one process per GPU, intervals sharded, no data-path
+collective: "weak" scaling, every rank evaluates its own 100 Mb shard).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one tehmm_eval_batch(VITERBI | POSTERIOR) over the rank's whole batch of intervals,
+observations already resident in HBM, results left in HBM (paths int64 + posteriors f64).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_STATES = 35
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def gen_obs_torch(model, lens, seed, device):
+    """Synthetic observations on the GPU (torch is plumbing here): state path made of geometric
+    runs (sticky chain like the model's diagonal), symbols drawn from each state's per-track
+    distribution by inverse-CDF.  Returns a uint8 [total, K] CUDA tensor."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    total = int(np.sum(lens))
+    N, K = model.n_states, model.n_tracks
+    stay = float(np.mean(np.diag(model.transmat)))
+    n_runs = int(total * (1.0 - stay) * 1.3) + 1024
+    u = torch.rand(n_runs, generator=g, device=device, dtype=torch.float64)
+    run_len = (torch.log1p(-u) / np.log(stay)).floor().to(torch.int64) + 1
+    run_state = torch.randint(0, N, (n_runs,), generator=g, device=device)
+    states = torch.repeat_interleave(run_state, run_len)[:total]
+    if states.numel() < total:
+        states = torch.cat([states, states.new_zeros(total - states.numel())])
+    del u, run_len, run_state
+    obs = torch.empty((total, K), dtype=torch.uint8, device=device)
+    for k, sk in enumerate(model.symbols_per_track):
+        cdf = np.cumsum(model.probs[k, :, 1:1 + sk], axis=1)
+        cdf[:, -1] = 1.0
+        flat = torch.tensor((cdf + np.arange(N)[:, None]).ravel(), device=device, dtype=torch.float64)
+        step = 1 << 24
+        for a in range(0, total, step):
+            st = states[a:a + step]
+            uu = torch.rand(st.numel(), generator=g, device=device, dtype=torch.float64) * 0.999999
+            idx = torch.searchsorted(flat, uu + st.to(torch.float64), right=True) - st * sk
+            obs[a:a + step, k] = (idx.clamp_(0, sk - 1) + 1).to(torch.uint8)
+    return obs
+
+
+def cpu_baseline(model, n_threads, per_interval, seed=123):
+    """Times the CPU oracle (a port of the reference's Cython loops, oracle/tehmm_oracle.c) on a
+    bounded sample of the same workload: the teHmmEval flow (score_samples + decode) per interval,
+    one interval per worker thread at a time."""
+    from oracle import oracle
+    from tehmm_amd import synth
+    n_iv = 4 * n_threads
+    lens = np.full(n_iv, per_interval, dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = synth.sample_obs(model, int(offs[-1]), seed=seed)
+    t0 = time.perf_counter()
+    oracle.eval_batch(obs, offs, model.log_probs, model.log_startprob, model.log_transmat,
+                      1.0, None, want_post=True, n_threads=n_threads)
+    dt = time.perf_counter() - t0
+    return {"value": float(offs[-1]) / dt, "unit": "positions/s", "cores": int(n_threads),
+            "kind": "port",
+            "sample": "%d intervals x %d positions, Viterbi + posterior, %d threads, %.1f s"
+                      % (n_iv, per_interval, n_threads, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mb", type=float, default=100.0, help="Mb of genome per GPU")
+    ap.add_argument("--min-kb", type=int, default=200, help="shortest interval (kb)")
+    ap.add_argument("--max-kb", type=int, default=2000, help="longest interval (kb)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-kb", type=int, default=250,
+                    help="positions per CPU-baseline interval (kb); 4 intervals per thread")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    from tehmm_amd import _lib, synth
+    from tehmm_amd.engine import HipBatch, HipModel
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    _lib.check(_lib.load().tehmm_set_device(local_rank), "tehmm_set_device")
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    model = synth.make_model(N_STATES, synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=0)
+    total = int(args.mb * 1e6)
+    lens = synth.interval_lengths(total, args.min_kb * 1000, args.max_kb * 1000, seed=1000 + rank)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = gen_obs_torch(model, lens, seed=17 + rank, device=device)
+    torch.cuda.synchronize()
+
+    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs,
+                  symbols_per_track=model.symbols_per_track)
+    hb = HipBatch(obs.data_ptr(), offs, device_ptrs=True, K=model.n_tracks)
+    del obs
+    torch.cuda.empty_cache()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        hm.eval(hb, viterbi=True, posterior=True)
+    kt = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hm.eval(hb, viterbi=True, posterior=True)
+        for name, ms in hb.timing().items():      # HIP events on the library's own streams
+            kt.setdefault(name, []).append(ms)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        K, N = model.n_tracks, model.n_states
+        pos_per_step = float(total) * world
+        value = pos_per_step * args.steps / dt
+        kavg = {k: float(np.mean(v)) for k, v in kt.items()}
+        dom = max(kavg, key=kavg.get)
+        # algorithmic bytes per position of each kernel:
+        #   viterbi: obs in (K) + int64 path out (8);  backward_posterior: obs in (K) + posterior
+        #   row out (8N);  forward: obs in (K);  traceback: path out (8)
+        alg = {"viterbi": K + 8, "backward_posterior": K + 8 * N, "forward": K, "traceback": 8,
+               "forward_backward": K, "posterior_combine": 8 * N}
+        achieved = alg[dom] * float(total) / (kavg[dom] * 1e-3) / 1e9
+        out = {
+            "metric": "genome positions/sec (Viterbi+posterior), 35 states x 10 tracks",
+            "value": value, "unit": "positions/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "teHmmEval Viterbi+posterior, 35 states, 10 tracks (8 multinomial "
+                                   "+ 2 gaussian/250 bins), %.0f Mb per GPU in %d intervals of "
+                                   "%d-%d kb (config-3 geometry), obs resident in HBM"
+                                   % (args.mb, len(lens), args.min_kb, args.max_kb),
+                       "positions_per_gpu": total, "intervals_per_gpu": int(len(lens)),
+                       "parallelism": "intervals sharded over %d GPU(s), no collective" % world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "alg_bytes_per_position": alg[dom],
+                         "whole_path_GBps": (K + 8 + 8 * N) * value / world / 1e9},
+            "kernel_ms": kavg,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            nthr = max(1, min(16, os.cpu_count() or 1))
+            out["cpu_baseline"] = cpu_baseline(model, nthr, args.cpu_sample_kb * 1000)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -135,6 +135,10 @@ int tehmm_estep_batch(tehmm_model_t *model, tehmm_batch_t *batch, int use_ratios
 int tehmm_batch_last_timing(tehmm_batch_t *batch, int max_entries, const char **names,
                             double *milliseconds);
 
+/* Diagnostic builds only (-DTEHMM_STAMPS): per-wave cycle stamps of the last cooperative kernel,
+ * [workgroup][wave][4] counters.  The product library returns TEHMM_ERR_UNSUPPORTED. */
+int tehmm_debug_read_stamps(unsigned long long *out, int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtehmm_hip.so")
+LIB_PATH = os.environ.get("TEHMM_HIP_LIB") or os.path.join(_HERE, "libtehmm_hip.so")
 
 f64p = ctypes.POINTER(ctypes.c_double)
 i64p = ctypes.POINTER(ctypes.c_int64)
@@ -46,6 +46,7 @@ SIGNATURES = {
     "tehmm_batch_device_ptrs": (c_int, [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]),
     "tehmm_estep_batch": (c_int, [vp, vp, c_int, f64p, f64p, f64p, f64p]),
     "tehmm_batch_last_timing": (c_int, [vp, c_int, ctypes.POINTER(ctypes.c_char_p), f64p]),
+    "tehmm_debug_read_stamps": (c_int, [ctypes.POINTER(ctypes.c_uint64), c_int]),
 }
 
 EVAL_VITERBI = 1

@@ -1,0 +1,610 @@
+// tehmm_coop.hip.h -- cooperative ("one workgroup per interval") kernels: the latency-bound regime.
+//
+// A teHmmEval batch is a few dozen to a few hundred long intervals, and every DP over one interval
+// is a strictly sequential chain (the Viterbi chain must even keep the reference's fp64 rounding
+// order), so the time of a batch is (longest interval) x (cycles per chain step).  These kernels
+// give every interval a whole workgroup of 4 wavefronts (one per SIMD of a CU) and strip the chain
+// wave down to the bare recurrence:
+//   * the chain wave runs only the value recurrence: lane = destination state, its column of the
+//     transition table in registers; the previous state vector reaches every lane partly by
+//     v_readlane (straight from the register, which covers the LDS write->read latency) and
+//     partly by LDS broadcast reads (ds_read_b128, two states per instruction);
+//   * helper waves compute, one 64-position block ahead, the emission rows (lane = position, so
+//     the table gathers of 64 positions are all in flight together; small tracks' tables are
+//     staged in LDS) and, one block behind, whatever is parallel over positions: the Viterbi
+//     arg-max / traceback pointers, recomputed from the stored value vectors in exactly the
+//     reference's operation order.
+// Blocks are handed over through LDS rings with one workgroup barrier per 64 positions.
+// NT = number of states padded to a multiple of 4 (compile time); padding states have -inf
+// transitions / zero probability.
+#pragma once
+#include "tehmm_kernels.hip.h"
+
+namespace tehmm {
+
+// LDS broadcast reads of a whole state vector: the row address is laundered through an opaque
+// v_mov so that it stays in ONE VGPR and the unrolled reads become
+// `ds_read_b128 v, vbase offset:imm` (one instruction each).
+typedef double d2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const d2v lds_cd2;
+__device__ __forceinline__ lds_cd2 *lds_row(const double *row) {
+  unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) const double *)row;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(a) : "v"(a));
+  return (lds_cd2 *)(size_t)a;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int wave_max_i32_dpp(int v) {
+  const int ident = (int)0x80000000;
+  v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+  v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x112, 0xf, 0xf, false));   // row_shr:2
+  v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x114, 0xf, 0xf, false));   // row_shr:4
+  v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x118, 0xf, 0xf, false));   // row_shr:8
+  v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x142, 0xa, 0xf, false));   // row_bcast:15
+  v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x143, 0xc, 0xf, false));   // row_bcast:31
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// exp(y) for y <= 0 (the only range the scaled emission needs): k = rint(y/ln2),
+// r = y - k*ln2 (two-piece ln2), degree-13 Taylor polynomial (|r| <= 0.347: truncation 4e-18),
+// ldexp.  About 1 ulp; ~22 VALU instructions instead of the generic libm path.
+__device__ __forceinline__ double exp_nonpos(double y) {
+  const double k = rint(y * 1.4426950408889634);
+  double r = fma(k, -6.93147180369123816490e-01, y);
+  r = fma(k, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;            // 1/13!
+  p = fma(p, r, 2.08767569878681e-09);          // 1/12!
+  p = fma(p, r, 2.505210838544172e-08);         // 1/11!
+  p = fma(p, r, 2.755731922398589e-07);         // 1/10!
+  p = fma(p, r, 2.7557319223985893e-06);        // 1/9!
+  p = fma(p, r, 2.48015873015873e-05);          // 1/8!
+  p = fma(p, r, 1.984126984126984e-04);         // 1/7!
+  p = fma(p, r, 1.388888888888889e-03);         // 1/6!
+  p = fma(p, r, 8.333333333333333e-03);         // 1/5!
+  p = fma(p, r, 4.1666666666666664e-02);        // 1/4!
+  p = fma(p, r, 1.6666666666666666e-01);        // 1/3!
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  const double res = ldexp(p, (int)k);
+  return y < -1100.0 ? 0.0 : res;               // also maps -inf to 0; NaN stays NaN
+}
+
+// Emission tables for the cooperative kernels: rows of tracks flagged in_lds are served from the
+// LDS copy `ltab` (row index lds_base[k] + symbol), the others from global memory.
+struct EmisLds {
+  const double *ltab;     // LDS [lds_rows][NT]
+};
+
+// Emission log-likelihood of ONE position per lane, all NT (padded) states in registers.
+// Operation order per state as in _emission.pyx:65-72.  Table rows are [NT] doubles (pads 0).
+template <int NT>
+__device__ __forceinline__ void emis_rows(const EmisTab &e, const double *ltab, int64_t gpos,
+                                          double (&x)[NT]) {
+  const uint32_t *row = e.obs32 + gpos * e.KPW;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) x[j] = 0.0;
+  uint32_t wn = row[0];
+  for (int d = 0; d < e.KPW; ++d) {
+    const uint32_t w = wn;
+    if (d + 1 < e.KPW) wn = row[d + 1];
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+      const int k = 4 * d + bb;
+      if (k < e.K) {
+        int sym = (int)((w >> (8 * bb)) & 0xffu);
+        sym = min(sym, e.rowcnt[k] - 1);
+        const int lb = e.ldsbase[k];
+        if (lb >= 0) {
+          lds_cd2 *tr = (lds_cd2 *)(size_t)((unsigned)(size_t)(
+              __attribute__((address_space(3))) const double *)ltab + (unsigned)((lb + sym) * NT * 8));
+#pragma unroll
+          for (int jj = 0; jj < NT / 2; ++jj) {
+            const d2v v = tr[jj];
+            x[2 * jj] += v.x;
+            x[2 * jj + 1] += v.y;
+          }
+        } else {
+          const double2 *tr = (const double2 *)(e.tab + (int64_t)(e.rowbase[k] + sym) * NT);
+#pragma unroll
+          for (int jj = 0; jj < NT / 2; ++jj) {
+            const double2 v = tr[jj];
+            x[2 * jj] += v.x;
+            x[2 * jj + 1] += v.y;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) x[j] *= e.normalize;
+  if (e.ratios) {
+    const double r = e.ratios[gpos];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) x[j] *= r;
+  }
+}
+
+// One block of up to 64 emission rows (lane = position) into an LDS ring, row stride RS doubles.
+//   LINEAR=false: log rows (Viterbi).   LINEAR=true: exp(row - rowmax) and rowmax to ms[].
+//   ASCENDING=true: blocks arrive in increasing t and the leading-rows quirk (_emission.pyx:73-80)
+//   is tracked in `seen`; a later impossible row sets *dead (the reference's lattices turn NaN).
+//   ASCENDING=false: every impossible row is zeroed (correct unless *dead gets set by the
+//   ascending pass of the same interval).
+template <int NT, bool LINEAR, bool ASCENDING, bool TRATIO>
+__device__ __forceinline__ void emis_block(const EmisTab &e, const double *ltab, int64_t gbase,
+                                           int np, int lane, int N, bool &seen, int *dead,
+                                           const double *ltdiag, const double *tratios,
+                                           double *ring, int RS, double *ms) {
+  const bool act = lane < np;
+  const int64_t gpos = gbase + (act ? lane : np - 1);
+  double x[NT];
+  emis_rows<NT>(e, ltab, gpos, x);
+  // pads (j >= N) hold 0.0 (table pads are zero); mask them out of the row maximum once
+  double m = x[0];
+#pragma unroll
+  for (int j = 1; j < NT; ++j) m = fmax(m, j < N ? x[j] : -INFINITY);
+  const bool good = m > -1e20;
+  bool zero;
+  if (ASCENDING) {
+    const unsigned long long gm = __ballot(good && act);
+    const int first = gm ? __ffsll((long long)gm) - 1 : 64;
+    zero = !seen && lane < first;
+    if (!good && !zero && act && dead) *dead = 1;
+    if (gm) seen = true;
+  } else {
+    zero = !good;
+  }
+  if (zero) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) x[j] = 0.0;
+    m = 0.0;
+  }
+  if (TRATIO) {
+    const double r = tratios[gpos];
+    if (r > 1.) {
+      m = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        x[j] += ltdiag[j] * (r - 1.);
+        m = fmax(m, j < N ? x[j] : -INFINITY);
+      }
+    }
+  }
+  if (act) {
+    double *dst = ring + lane * RS;
+    if (LINEAR) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) dst[j] = j < N ? exp_nonpos(x[j] - m) : 0.0;
+      ms[lane] = m;
+    } else {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) dst[j] = x[j];
+    }
+  }
+}
+
+// copies the LDS-resident part of the emission table (rows [0, lds_rows) of e.ltab_src)
+__device__ __forceinline__ void stage_emis_table(const EmisTab &e, double *ltab, int NT) {
+  const int n = e.lds_rows * NT;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) ltab[i] = e.ltab_src[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// Cooperative Viterbi.  blockDim = 256.  Byte traceback table tb[(pos0 + t) * NT + state].
+//   wave 0      : value chain.  V_t[to] = max( c0 , max_{from>=1} x_from (+b, +ratio term) ) where
+//                 x_from = V_{t-1}[from] + lt[from][to]; hoisting "+ b" out of the max is exact
+//                 because fp64 rounding is monotone (the ARG-max is not hoisted: see below).
+//   wave 1      : emission rows of block it;
+//   waves 2, 3  : the exact arg-max of block it-2 (positions split even / odd):
+//                 lane = to, c_from recomputed in the reference's order (V+lt)+b [+ratio term],
+//                 arg = lowest from with c_from == V_t[to] (== the reference's strict '>' scan).
+// LDS (doubles): bring [3][CPB][RS] | Vring [2][CPB+1][NT] | ltab [lds_rows][NT]
+// ------------------------------------------------------------------------------------------
+template <int NT, int CPB, bool RATIO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_vit_coop(IntervalTab iv, EmisTab em, int N, const double *g_lt, const double *g_pi,
+                const double *tratios, uint8_t *tb, int *last_state, double *logprob) {
+  extern __shared__ double sm[];
+  constexpr int RS = NT + 1;
+  double *bring = sm;
+  double *Vring = bring + 3 * CPB * RS;
+  double *ltab = Vring + 2 * (CPB + 1) * NT;
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int id = iv.order[blockIdx.x];
+  const int64_t T = iv.len[id];
+  const int64_t p0 = iv.pos0[id];
+  if (T <= 0) return;
+  stage_emis_table(em, ltab, NT);
+  const int jl = min(lane, NT - 1);
+  const bool live = lane < N;
+  ST_DECL;
+  __syncthreads();
+  const int64_t nb = (T + CPB - 1) / CPB;
+  // Every role runs its own loop over the block iterations (so that its registers are not live in
+  // the other roles' code); all of them execute the same nb + 2 workgroup barriers.
+  if (w == 0) {
+    // ============================================================== value chain (block it-1)
+    double ltc[NT];   // column `lane` of lt; pad lanes: -inf so their value stays -inf unmasked
+#pragma unroll
+    for (int f = 0; f < NT; ++f) ltc[f] = live ? g_lt[f * NT + jl] : -INFINITY;
+    const double ltd = live ? g_lt[jl * NT + jl] : 0.0;
+    const double lt00 = g_lt[0];
+    const double pij = live ? g_pi[jl] : -INFINITY;
+    double vcur = -INFINITY;
+    for (int64_t it = 0; it < nb + 2; ++it) {
+      ST_BEGIN;
+      const int64_t bn = it - 1;
+      if (bn >= 0 && bn < nb) {
+        const int np = (int)min((int64_t)CPB, T - bn * CPB);
+        double *Vr = Vring + (bn & 1) * (CPB + 1) * NT;
+        const double *br = bring + (bn % 3) * CPB * RS;
+        if (bn > 0 && lane < NT) Vr[lane] = vcur;
+        for (int p = 0; p < np; ++p) {
+          const int64_t t = bn * CPB + p;
+          const double b = br[p * RS + jl];
+          double r = 0.0;
+          if (RATIO) r = tratios[p0 + t];
+          double v;
+          if (t == 0) {
+            v = pij + b;
+            if (RATIO && r > 1.) v += ltd * (r - 1.);
+          } else {
+            __builtin_amdgcn_wave_barrier();
+            lds_cd2 *vp = lds_row(Vr + p * NT);
+            d2v pv[NT / 2];
+#pragma unroll
+            for (int f2 = 0; f2 < NT / 2; ++f2) pv[f2] = vp[f2];   // all broadcast reads in flight
+            // x_from = V[from] + lt[from][to]: NT independent adds, then a max tree
+            double x[NT];
+#pragma unroll
+            for (int f2 = 0; f2 < NT / 2; ++f2) {
+              x[2 * f2] = pv[f2].x + ltc[2 * f2];
+              x[2 * f2 + 1] = pv[f2].y + ltc[2 * f2 + 1];
+            }
+            double c0 = x[0] + b;
+            x[0] = -INFINITY;
+#pragma unroll
+            for (int n = NT; n > 1; n = (n + 1) / 2) {
+#pragma unroll
+              for (int i = 0; i < n / 2; ++i) x[i] = fmax(x[i], x[i + (n + 1) / 2]);
+            }
+            if (RATIO) {
+              c0 += ltd * r;
+              if (lane == 0) c0 -= lt00;
+            }
+            double c1 = x[0] + b;
+            if (RATIO && r > 1.) c1 += ltd * (r - 1.);
+            v = c1 > c0 ? c1 : c0;      // c0 NaN stays (reference: nothing is '>' a NaN best)
+          }
+          vcur = v;
+          if (lane < NT) Vr[(p + 1) * NT + lane] = v;
+        }
+      }
+      ST_ADD(st_a);
+      __syncthreads();
+      ST_ADD(st_c);
+    }
+    ST_FLUSH(w);
+    double *scratch = Vring;
+    if (lane < NT) scratch[lane] = vcur;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      int last = 0;
+      double m = scratch[0];
+      if (m == m) {
+        for (int j = 1; j < N; ++j) {
+          double x = scratch[j];
+          if (x != x) { last = j; break; }
+          if (x > m) { m = x; last = j; }
+        }
+      }
+      last_state[id] = last;
+      logprob[id] = scratch[last];
+    }
+  } else if (w == 1) {
+    // ============================================================== emission rows (block it)
+    bool seen = false;
+    for (int64_t it = 0; it < nb + 2; ++it) {
+      ST_BEGIN;
+#ifdef TEHMM_DBG_NOEMIS
+      if (it < 3) {
+#else
+      if (it < nb) {
+#endif
+        const int np = (int)min((int64_t)CPB, T - it * CPB);
+        emis_block<NT, false, true, false>(em, ltab, p0 + it * CPB, np, lane, N, seen, nullptr,
+                                           nullptr, nullptr, bring + (it % 3) * CPB * RS, RS,
+                                           nullptr);
+      }
+      ST_ADD(st_a);
+      __syncthreads();
+      ST_ADD(st_c);
+    }
+    ST_FLUSH(w);
+  } else {
+    // ============================================================== exact arg-max (block it-2)
+    // lane = to; c_from recomputed in the reference's order (V+lt)+b [+ratio term];
+    // arg = lowest from with c_from == V_t[to] (== the reference's strict '>' ascending scan).
+    double ltc[NT];
+#pragma unroll
+    for (int f = 0; f < NT; ++f) ltc[f] = live ? g_lt[f * NT + jl] : -INFINITY;
+    const double ltd = live ? g_lt[jl * NT + jl] : 0.0;
+    const double lt00 = g_lt[0];
+    for (int64_t it = 0; it < nb + 2; ++it) {
+      ST_BEGIN;
+      const int64_t ba = it - 2;
+#ifdef TEHMM_DBG_NOARGS
+      if (ba >= 0 && ba < 1) {
+#else
+      if (ba >= 0 && ba < nb) {
+#endif
+        const int np = (int)min((int64_t)CPB, T - ba * CPB);
+        const double *Vr = Vring + (ba & 1) * (CPB + 1) * NT;
+        const double *br = bring + (ba % 3) * CPB * RS;
+        for (int p = w - 2; p < np; p += 2) {
+          const int64_t t = ba * CPB + p;
+          if (t == 0) continue;
+          lds_cd2 *vp = lds_row(Vr + p * NT);
+          d2v pv[NT / 2];
+#pragma unroll
+          for (int f2 = 0; f2 < NT / 2; ++f2) pv[f2] = vp[f2];
+          const double vt = Vr[(p + 1) * NT + jl];
+          const double b = br[p * RS + jl];
+          double c[NT];
+#pragma unroll
+          for (int f2 = 0; f2 < NT / 2; ++f2) {
+            c[2 * f2] = pv[f2].x + ltc[2 * f2];
+            c[2 * f2 + 1] = pv[f2].y + ltc[2 * f2 + 1];
+          }
+#pragma unroll
+          for (int f = 0; f < NT; ++f) c[f] += b;
+          if (RATIO) {
+            const double r = tratios[p0 + t];
+            c[0] += ltd * r;
+            if (lane == 0) c[0] -= lt00;
+            if (r > 1.) {
+              const double addr = ltd * (r - 1.);
+#pragma unroll
+              for (int f = 1; f < NT; ++f) c[f] += addr;
+            }
+          }
+          int arg = 0;
+#pragma unroll
+          for (int f = NT - 1; f >= 1; --f) arg = c[f] == vt ? f : arg;
+          arg = c[0] == vt ? 0 : arg;
+          if (live) tb[(p0 + t) * NT + lane] = (uint8_t)arg;
+        }
+      }
+      ST_ADD(st_b);
+      __syncthreads();
+      ST_ADD(st_c);
+    }
+    ST_FLUSH(w);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Cooperative forward + backward (scaled linear domain, see k_forward_lin / k_backward_lin).
+// blockDim = 256: wave 0 forward chain, wave 1 backward chain, wave 2 / 3 their emission rows.
+// alpha rows go to `alpha` ([total][N], the posterior buffer), beta rows to `beta`.
+// Lane NT-1 is always a padding lane (N < NT): it carries a column of ones, so the same FMA loop
+// leaves in it the SUM of the previous vector, whose binary exponent is the power-of-two scale of
+// the step -- no cross-lane reduction on the chain.
+// LDS (doubles): ringF [2][CPB][RS] | ringB [2][CPB][RS] | msF [2][CPB] | msB [2][CPB] |
+//                xF [2][NT] | xB [2][NT] | ltd [NT] | ltab [lds_rows][NT]
+// ------------------------------------------------------------------------------------------
+template <int NT, int CPB, bool TRATIO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_fb_coop(IntervalTab iv, EmisTab em, int N, const double *g_A, const double *g_lt,
+               const double *g_pi, const double *tratios, double *alpha, double *beta,
+               double *fwd_logprob, int *dead_flag) {
+  extern __shared__ double sm[];
+  constexpr int RS = NT + 1;
+  double *ringF = sm;
+  double *ringB = ringF + 2 * CPB * RS;
+  double *msF = ringB + 2 * CPB * RS;
+  double *msB = msF + 2 * CPB;
+  double *xF = msB + 2 * CPB;
+  double *xB = xF + 2 * NT;
+  double *ltdv = xB + 2 * NT;
+  double *ltab = ltdv + NT;
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int id = iv.order[blockIdx.x];
+  const int64_t T = iv.len[id];
+  const int64_t p0 = iv.pos0[id];
+  if (T <= 0) return;
+  const int jl = min(lane, NT - 1);
+  const bool live = lane < N;
+  if (threadIdx.x < NT) ltdv[threadIdx.x] = g_lt[threadIdx.x * NT + threadIdx.x];
+  stage_emis_table(em, ltab, NT);
+  ST_DECL;
+  __syncthreads();
+  const int64_t nb = (T + CPB - 1) / CPB;
+  if (w == 0) {
+    // ============================================================== forward chain (block it-1)
+    double ac[NT];   // column jl of A (A[i][jl]); pad lane NT-1: ones
+#pragma unroll
+    for (int i = 0; i < NT; ++i) ac[i] = live ? g_A[i * NT + jl] : (lane == NT - 1 ? 1.0 : 0.0);
+    double *al = alpha + iv.out0[id] * N;
+    double Ecum = 0.0, Mcum = 0.0, a = 0.0;
+    for (int64_t it = 0; it < nb + 1; ++it) {
+      ST_BEGIN;
+      const int64_t bn = it - 1;
+      if (bn >= 0) {
+        const int np = (int)min((int64_t)CPB, T - bn * CPB);
+        const double *br = ringF + (bn & 1) * CPB * RS;
+        const double *mr = msF + (bn & 1) * CPB;
+        for (int p = 0; p < np; ++p) {
+          const int64_t t = bn * CPB + p;
+          const double bh = br[p * RS + jl];
+          Mcum += mr[p];
+          if (t == 0) {
+            a = live ? exp(g_pi[jl]) * bh : 0.0;
+          } else {
+            __builtin_amdgcn_wave_barrier();
+            lds_cd2 *vp = lds_row(xF + ((t - 1) & 1) * NT);
+            d2v pv[NT / 2];
+#pragma unroll
+            for (int f2 = 0; f2 < NT / 2; ++f2) pv[f2] = vp[f2];
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int f4 = 0; f4 < NT / 4; ++f4) {
+              s0 = fma(pv[2 * f4].x, ac[4 * f4], s0);
+              s1 = fma(pv[2 * f4].y, ac[4 * f4 + 1], s1);
+              s2 = fma(pv[2 * f4 + 1].x, ac[4 * f4 + 2], s2);
+              s3 = fma(pv[2 * f4 + 1].y, ac[4 * f4 + 3], s3);
+            }
+            const double ssum = (s0 + s1) + (s2 + s3);
+            // lane NT-1 holds sum_i a_{t-1}[i]: its exponent scales this step
+            const int e = ((__builtin_amdgcn_readlane(__double2hiint(ssum), NT - 1) >> 20) & 0x7ff) - 1022;
+            a = live ? ldexp(ssum * bh, -e) : 0.0;
+            Ecum += (double)e;
+          }
+          if (lane < NT) xF[(t & 1) * NT + lane] = a;
+          if (live) al[t * N + lane] = a;
+        }
+      }
+      ST_ADD(st_a);
+      __syncthreads();
+      ST_ADD(st_c);
+    }
+    ST_FLUSH(w);
+    double tot = wave_sum_f64(live ? a : 0.0);
+    if (lane == 0) fwd_logprob[id] = log(tot) + Ecum * 0.6931471805599453 + Mcum;
+  } else if (w == 1) {
+    // ============================================================== backward chain (block it-1)
+    double ac[NT];   // row jl of A (A[jl][j]); pad lane NT-1: ones
+#pragma unroll
+    for (int j = 0; j < NT; ++j) ac[j] = live ? g_A[jl * NT + j] : (lane == NT - 1 ? 1.0 : 0.0);
+    double *be = beta + iv.out0[id] * N;
+    double bt = 0.0;
+    for (int64_t it = 0; it < nb + 1; ++it) {
+      ST_BEGIN;
+      const int64_t bn = it - 1;
+      if (bn >= 0) {
+        const int64_t uhi = T - bn * CPB;
+        const int64_t ulo = max((int64_t)0, uhi - CPB);
+        const double *br = ringB + (bn & 1) * CPB * RS;
+        for (int64_t u = uhi - 1; u >= ulo; --u) {
+          // w[u+1] = bh'[u+1] * beta[u+1] (lane = state) feeds beta[u]; beta[T-1] = 1
+          const double bh = br[(int)(u - ulo) * RS + jl];
+          if (u == T - 1) {
+            bt = live ? 1.0 : 0.0;
+          } else {
+            __builtin_amdgcn_wave_barrier();
+            lds_cd2 *vp = lds_row(xB + ((u + 1) & 1) * NT);
+            d2v pv[NT / 2];
+#pragma unroll
+            for (int f2 = 0; f2 < NT / 2; ++f2) pv[f2] = vp[f2];
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int f4 = 0; f4 < NT / 4; ++f4) {
+              s0 = fma(ac[4 * f4], pv[2 * f4].x, s0);
+              s1 = fma(ac[4 * f4 + 1], pv[2 * f4].y, s1);
+              s2 = fma(ac[4 * f4 + 2], pv[2 * f4 + 1].x, s2);
+              s3 = fma(ac[4 * f4 + 3], pv[2 * f4 + 1].y, s3);
+            }
+            const double ssum = (s0 + s1) + (s2 + s3);
+            const int e = ((__builtin_amdgcn_readlane(__double2hiint(ssum), NT - 1) >> 20) & 0x7ff) - 1022;
+            bt = live ? ldexp(ssum, -e) : 0.0;
+          }
+          if (live) be[u * N + lane] = bt;
+          const double wv = live ? bh * bt : 0.0;
+          if (lane < NT) xB[(u & 1) * NT + lane] = wv;
+        }
+      }
+      ST_ADD(st_a);
+      __syncthreads();
+      ST_ADD(st_c);
+    }
+    ST_FLUSH(w);
+  } else if (w == 2) {
+    // ============================================================== forward emission (block it)
+    bool seen = false;
+    for (int64_t it = 0; it < nb + 1; ++it) {
+      ST_BEGIN;
+      if (it < nb) {
+        const int np = (int)min((int64_t)CPB, T - it * CPB);
+        emis_block<NT, true, true, TRATIO>(em, ltab, p0 + it * CPB, np, lane, N, seen, dead_flag + id,
+                                           ltdv, tratios, ringF + (it & 1) * CPB * RS, RS,
+                                           msF + (it & 1) * CPB);
+      }
+      ST_ADD(st_a);
+      __syncthreads();
+      ST_ADD(st_c);
+    }
+    ST_FLUSH(w);
+  } else {
+    // ============================================================== backward emission (block it)
+    // block it covers positions u in [T - (it+1)*CPB, T - it*CPB) clipped at 0, stored ascending
+    // inside the ring (slot = u - ulo)
+    for (int64_t it = 0; it < nb + 1; ++it) {
+      ST_BEGIN;
+      if (it < nb) {
+        const int64_t uhi = T - it * CPB;
+        const int64_t ulo = max((int64_t)0, uhi - CPB);
+        bool dummy = true;
+        emis_block<NT, true, false, TRATIO>(em, ltab, p0 + ulo, (int)(uhi - ulo), lane, N, dummy,
+                                            nullptr, ltdv, tratios, ringB + (it & 1) * CPB * RS, RS,
+                                            msB + (it & 1) * CPB);
+      }
+      ST_ADD(st_a);
+      __syncthreads();
+      ST_ADD(st_c);
+    }
+    ST_FLUSH(w);
+  }
+}
+
+// posterior rows from alpha / beta rows: post = normalise(alpha * beta) [+ float32 eps quirk of
+// score_samples, basehmm.py:271-272].  One wave per row, lane = state; in place into alpha.
+template <bool EPS>
+__global__ __launch_bounds__(256) void k_combine(int64_t rows, int N, double *alpha,
+                                                 const double *beta) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const double eps = 1.1920928955078125e-07;
+  const double epsden = 1.0 + (double)N * eps;
+  for (int64_t r0 = wid * 4; r0 < rows; r0 += nw * 4) {
+    double g[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t r = r0 + k;
+      g[k] = 0.0;
+      if (r < rows && lane < N) g[k] = alpha[r * N + lane] * beta[r * N + lane];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t r = r0 + k;
+      const double tot = wave_sum_f64(g[k]);
+      double pr = g[k] / tot;
+      if (EPS) pr = (pr + eps) / epsden;
+      if (r < rows && lane < N) alpha[r * N + lane] = pr;
+    }
+  }
+}
+// intervals whose forward pass met an impossible row after the first emittable one: the
+// reference's lattices are NaN from there on; make the outputs say so.
+__global__ void k_poison_dead(IntervalTab iv, const int *dead_flag, int N, double *post,
+                              double *fwd_logprob) {
+  const int id = blockIdx.y;
+  if (id >= iv.n || !dead_flag[id]) return;
+  const int64_t T = iv.len[id];
+  double *o = post + iv.out0[id] * N;
+  const double nan = __longlong_as_double(0x7ff8000000000000LL);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < T * N;
+       i += (int64_t)gridDim.x * blockDim.x)
+    o[i] = nan;
+  if (blockIdx.x == 0 && threadIdx.x == 0) fwd_logprob[id] = nan;
+}
+
+}  // namespace tehmm

@@ -1,6 +1,7 @@
 // tehmm_hip.hip -- host side of libtehmm_hip.so: the C ABI declared in include/tehmm_hip.h.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see tehmm_amd/build.py).
 #include "tehmm_kernels.hip.h"
+#include "tehmm_coop.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -66,6 +67,14 @@ int grid_for(int64_t work, int block, int cap = 8192) {
 
 constexpr int kMaxStates = 128;
 
+// padded state count: the cooperative kernels are instantiated for these sizes
+int pad_states(int N) {
+  static const int sizes[] = {4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 48, 56, 64};
+  for (int s : sizes)
+    if (N < s) return s;      // strictly greater: the last lane of the tile is always a pad lane
+  return (N + 4) & ~3;
+}
+
 // Dynamic LDS above the default limit has to be requested per kernel function.
 template <typename F>
 void allow_lds(F *fn, size_t bytes) {
@@ -77,9 +86,11 @@ void allow_lds(F *fn, size_t bytes) {
 struct tehmm_model {
   int N = 0, NP = 0, K = 0, S = 0, R = 0;
   double normalize = 1.0;
-  DBuf<double> lt, A, AT, pi, tab;
+  DBuf<double> lt, A, AT, pi, tab, ltab;
   int rowbase[TEHMM_MAX_TRACKS];
   int rowcnt[TEHMM_MAX_TRACKS];
+  int ldsbase[TEHMM_MAX_TRACKS];
+  int lds_rows = 0;
   std::vector<double> h_lt;   // [N][N] host copy (diag etc.)
 };
 
@@ -100,8 +111,10 @@ struct tehmm_batch {
   int N = 0, NP = 0, TBW = 0;
   DBuf<int64_t> paths;
   DBuf<double> post;
-  DBuf<uint32_t> tb;
+  DBuf<uint8_t> tb;
   DBuf<uint8_t> G, bstate;
+  DBuf<double> beta;
+  DBuf<int> dead;
   DBuf<int> last_state;
   DBuf<double> vit_lp, fwd_lp;
   DBuf<int64_t> first_good;
@@ -262,11 +275,12 @@ int tehmm_model_create(int N, int K, int S, const double *lt, const double *pi,
   m->N = N;
   m->K = K;
   m->S = S;
-  m->NP = (N + 1) & ~1;
+  m->NP = pad_states(N);
   m->normalize = normalize;
   const int NP = m->NP;
-  std::vector<double> hlt((size_t)N * NP, 0.0), hA((size_t)N * NP, 0.0), hAT((size_t)N * NP, 0.0),
-      hpi(NP, 0.0);
+  // tables are [NP][NP]; padding states have -inf log-transitions / zero probability
+  std::vector<double> hlt((size_t)NP * NP, -INFINITY), hA((size_t)NP * NP, 0.0),
+      hAT((size_t)NP * NP, 0.0), hpi(NP, -INFINITY);
   for (int i = 0; i < N; ++i) {
     hpi[i] = pi[i];
     for (int j = 0; j < N; ++j) {
@@ -296,7 +310,30 @@ int tehmm_model_create(int N, int K, int S, const double *lt, const double *pi,
     for (int s = 0; s < m->rowcnt[k]; ++s)
       for (int j = 0; j < N; ++j)
         htab[(size_t)(m->rowbase[k] + s) * NP + j] = logProbs[((size_t)k * N + j) * S + s];
+  // Small tracks' rows are staged in LDS by the cooperative kernels: smallest tracks first while
+  // they fit the budget (the 250-bin gaussian tracks stay in global memory / L2).
+  {
+    const size_t budget_rows = (size_t)(32 * 1024) / ((size_t)NP * sizeof(double));
+    std::vector<int> ord(K);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return m->rowcnt[a] < m->rowcnt[b]; });
+    for (int k = 0; k < K; ++k) m->ldsbase[k] = -1;
+    int used = 0;
+    for (int k : ord) {
+      if ((size_t)(used + m->rowcnt[k]) > budget_rows) break;
+      m->ldsbase[k] = used;
+      used += m->rowcnt[k];
+    }
+    m->lds_rows = used;
+  }
+  std::vector<double> hltab((size_t)std::max(1, m->lds_rows) * NP, 0.0);
+  for (int k = 0; k < K; ++k)
+    if (m->ldsbase[k] >= 0)
+      for (int s = 0; s < m->rowcnt[k]; ++s)
+        for (int j = 0; j < NP; ++j)
+          hltab[(size_t)(m->ldsbase[k] + s) * NP + j] = htab[(size_t)(m->rowbase[k] + s) * NP + j];
   hipError_t e = m->lt.upload(hlt.data(), hlt.size());
+  if (e == hipSuccess) e = m->ltab.upload(hltab.data(), hltab.size());
   if (e == hipSuccess) e = m->A.upload(hA.data(), hA.size());
   if (e == hipSuccess) e = m->AT.upload(hAT.data(), hAT.size());
   if (e == hipSuccess) e = m->pi.upload(hpi.data(), hpi.size());
@@ -437,6 +474,9 @@ static void fill_tabs(const tehmm_model *m, const tehmm_batch *b, IntervalTab &i
   em.NP = m->NP;
   std::memcpy(em.rowbase, m->rowbase, sizeof(em.rowbase));
   std::memcpy(em.rowcnt, m->rowcnt, sizeof(em.rowcnt));
+  std::memcpy(em.ldsbase, m->ldsbase, sizeof(em.ldsbase));
+  em.lds_rows = m->lds_rows;
+  em.ltab_src = m->ltab.p;
 }
 
 static int ensure_workspace(tehmm_batch *b, const tehmm_model *m, int flags) {
@@ -445,13 +485,14 @@ static int ensure_workspace(tehmm_batch *b, const tehmm_model *m, int flags) {
     b->post.release();
     b->tb.release();
     b->G.release();
+    b->beta.release();
     b->N = m->N;
     b->NP = m->NP;
     b->TBW = m->NP;
   }
   if ((flags & TEHMM_EVAL_VITERBI) && !b->paths.p) {
     HIPCHK(b->paths.alloc((size_t)b->total + 1));
-    HIPCHK(b->tb.alloc((size_t)(b->total_pad / 4 + 1) * b->TBW));
+    HIPCHK(b->tb.alloc((size_t)(b->total_pad + 1) * b->TBW));
     HIPCHK(b->G.alloc((size_t)(b->n_chunks + 1) * b->NP));
     HIPCHK(b->bstate.alloc((size_t)b->n_chunks + 1));
     HIPCHK(b->last_state.alloc((size_t)b->n + 1));
@@ -461,6 +502,8 @@ static int ensure_workspace(tehmm_batch *b, const tehmm_model *m, int flags) {
     HIPCHK(b->post.alloc((size_t)b->total * m->N + 1));
     HIPCHK(b->fwd_lp.alloc((size_t)b->n + 1));
     HIPCHK(b->first_good.alloc((size_t)b->n + 1));
+    HIPCHK(b->dead.alloc((size_t)b->n + 1));
+    if (m->N < 64) HIPCHK(b->beta.alloc((size_t)b->total * m->N + 1));
   }
   return TEHMM_OK;
 }
@@ -496,6 +539,45 @@ static void launch_posterior(tehmm_batch *b, const tehmm_model *m, const Interva
                      m->NP, m->AT.p, m->lt.p, (const double *)nullptr, b->post.p, b->first_good.p);
 }
 
+// ---- cooperative (one workgroup per interval) path, N <= 64 --------------------------------
+template <int NT>
+static void launch_vit_coop(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv,
+                            const EmisTab &em, bool ratio, hipStream_t st) {
+  constexpr int CPB = NT <= 44 ? 64 : 32;
+  size_t lds = ((size_t)3 * CPB * (NT + 1) + 2 * (CPB + 1) * NT + (size_t)m->lds_rows * NT) * sizeof(double);
+  if (ratio) {
+    allow_lds(k_vit_coop<NT, CPB, true>, lds);
+    hipLaunchKernelGGL((k_vit_coop<NT, CPB, true>), dim3(b->n), dim3(256), lds, st, iv, em, m->N,
+                       m->lt.p, m->pi.p, b->ratios.p, b->tb.p, b->last_state.p, b->vit_lp.p);
+  } else {
+    allow_lds(k_vit_coop<NT, CPB, false>, lds);
+    hipLaunchKernelGGL((k_vit_coop<NT, CPB, false>), dim3(b->n), dim3(256), lds, st, iv, em, m->N,
+                       m->lt.p, m->pi.p, (const double *)nullptr, b->tb.p, b->last_state.p,
+                       b->vit_lp.p);
+  }
+}
+
+template <int NT>
+static void launch_fb_coop(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv,
+                           const EmisTab &em, hipStream_t st) {
+  constexpr int CPB = NT <= 44 ? 64 : 32;
+  size_t lds = ((size_t)4 * CPB * (NT + 1) + 4 * CPB + 5 * NT + (size_t)m->lds_rows * NT) * sizeof(double);
+  allow_lds(k_fb_coop<NT, CPB, false>, lds);
+  hipLaunchKernelGGL((k_fb_coop<NT, CPB, false>), dim3(b->n), dim3(256), lds, st, iv, em, m->N, m->A.p,
+                     m->lt.p, m->pi.p, (const double *)nullptr, b->post.p, b->beta.p, b->fwd_lp.p,
+                     b->dead.p);
+}
+
+#define TEHMM_NT_DISPATCH(NP_, CALL)                                                                \
+  switch (NP_) {                                                                                    \
+    case 4: CALL(4); break;   case 8: CALL(8); break;   case 12: CALL(12); break;                   \
+    case 16: CALL(16); break; case 20: CALL(20); break; case 24: CALL(24); break;                   \
+    case 28: CALL(28); break; case 32: CALL(32); break; case 36: CALL(36); break;                   \
+    case 40: CALL(40); break; case 48: CALL(48); break; case 56: CALL(56); break;                   \
+    case 64: CALL(64); break;                                                                       \
+    default: break;                                                                                 \
+  }
+
 int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *viterbi_logprob,
                      double *forward_logprob) {
   if (!m || !b) return fail(TEHMM_ERR_ARG, "tehmm_eval_batch: NULL handle");
@@ -513,11 +595,16 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   EmisTab em;
   fill_tabs(m, b, iv, em, false);   // decode / score_samples never apply ratios to emissions
   const int SPL = m->N <= 64 ? 1 : 2;
+  const bool coop = m->N < 64;
   int evi = 0;
   if (flags & TEHMM_EVAL_VITERBI) {
     hipStream_t st = b->sV;
     (void)hipEventRecord(b->ev[evi], st);
-    if (SPL == 1) launch_viterbi<1>(b, m, iv, em, ratio, st);
+    if (coop) {
+#define CALL(NT_) launch_vit_coop<NT_>(b, m, iv, em, ratio, st)
+      TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+    } else if (SPL == 1) launch_viterbi<1>(b, m, iv, em, ratio, st);
     else launch_viterbi<2>(b, m, iv, em, ratio, st);
     (void)hipEventRecord(b->ev[evi + 1], st);
     if (b->n_chunks > 0)
@@ -539,12 +626,22 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   if (flags & TEHMM_EVAL_POSTERIOR) {
     hipStream_t st = b->sP;
     (void)hipEventRecord(b->ev[evi], st);
-    if (SPL == 1) launch_posterior<1>(b, m, iv, em, st, b->ev[evi + 1]);
+    if (coop) {
+      (void)hipMemsetAsync(b->dead.p, 0, (size_t)(b->n + 1) * sizeof(int), st);
+#define CALL(NT_) launch_fb_coop<NT_>(b, m, iv, em, st)
+      TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+      (void)hipEventRecord(b->ev[evi + 1], st);
+      hipLaunchKernelGGL((k_combine<true>), dim3(grid_for(b->total * 16, 256, 256 * 16)), dim3(256), 0, st,
+                         b->total, m->N, b->post.p, b->beta.p);
+      hipLaunchKernelGGL(k_poison_dead, dim3(64, b->n), dim3(256), 0, st, iv, b->dead.p, m->N, b->post.p,
+                         b->fwd_lp.p);
+    } else if (SPL == 1) launch_posterior<1>(b, m, iv, em, st, b->ev[evi + 1]);
     else launch_posterior<2>(b, m, iv, em, st, b->ev[evi + 1]);
     (void)hipEventRecord(b->ev[evi + 2], st);
-    b->tnames.push_back("forward");
+    b->tnames.push_back(coop ? "forward_backward" : "forward");
     b->tpairs.push_back({evi, evi + 1});
-    b->tnames.push_back("backward_posterior");
+    b->tnames.push_back(coop ? "posterior_combine" : "backward_posterior");
     b->tpairs.push_back({evi + 1, evi + 2});
     evi += 3;
   }
@@ -607,8 +704,8 @@ int tehmm_viterbi(int64_t T, int N, const double *pi, const double *lt, const do
     return fail(TEHMM_ERR_ARG, "tehmm_viterbi: bad argument");
   if (N > kMaxStates) return fail(TEHMM_ERR_UNSUPPORTED, "tehmm_viterbi: N > 128");
   if (T == 0) return TEHMM_OK;
-  const int NP = (N + 1) & ~1;
-  std::vector<double> hlt((size_t)N * NP, 0.0), hpi(NP, 0.0);
+  const int NP = pad_states(N);
+  std::vector<double> hlt((size_t)NP * NP, -INFINITY), hpi(NP, -INFINITY);
   for (int i = 0; i < N; ++i) {
     hpi[i] = pi[i];
     for (int j = 0; j < N; ++j) hlt[(size_t)i * NP + j] = lt[(size_t)i * N + j];
@@ -623,7 +720,7 @@ int tehmm_viterbi(int64_t T, int N, const double *pi, const double *lt, const do
   DBuf<double> d_lt, d_pi, d_fr, d_r, d_lp;
   DBuf<int64_t> d_off, d_pos0, d_len, d_chunk0, d_paths;
   DBuf<int> d_order, d_chunk_iv, d_last;
-  DBuf<uint32_t> d_tb;
+  DBuf<uint8_t> d_tb;
   DBuf<uint8_t> d_G, d_bs;
   HIPCHK(d_lt.upload(hlt.data(), hlt.size()));
   HIPCHK(d_pi.upload(hpi.data(), hpi.size()));
@@ -640,7 +737,7 @@ int tehmm_viterbi(int64_t T, int N, const double *pi, const double *lt, const do
   HIPCHK(d_order.upload(h_order, 1));
   HIPCHK(d_chunk_iv.upload(chunk_iv.data(), chunk_iv.size()));
   HIPCHK(d_paths.alloc((size_t)T));
-  HIPCHK(d_tb.alloc((size_t)(Tpad / 4 + 1) * NP));
+  HIPCHK(d_tb.alloc((size_t)(Tpad + 1) * NP));
   HIPCHK(d_G.alloc((size_t)(nch + 1) * NP));
   HIPCHK(d_bs.alloc((size_t)nch + 1));
   HIPCHK(d_last.alloc(1));
@@ -685,3 +782,15 @@ int tehmm_estep_batch(tehmm_model_t *m, tehmm_batch_t *b, int use_ratios, double
   return fail(TEHMM_ERR_UNSUPPORTED, "tehmm_estep_batch: not built yet");
 }
 
+
+// Diagnostic: cycle stamps of the last cooperative kernel (only in the -DTEHMM_STAMPS build).
+int tehmm_debug_read_stamps(unsigned long long *out, int n) {
+#ifdef TEHMM_STAMPS
+  if (!out || n <= 0 || n > 4096 * 16) return fail(TEHMM_ERR_ARG, "tehmm_debug_read_stamps: bad argument");
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), (size_t)n * sizeof(unsigned long long)));
+  return TEHMM_OK;
+#else
+  (void)out; (void)n;
+  return fail(TEHMM_ERR_UNSUPPORTED, "tehmm_debug_read_stamps: library built without -DTEHMM_STAMPS");
+#endif
+}

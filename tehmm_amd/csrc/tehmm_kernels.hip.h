@@ -24,6 +24,32 @@
 
 namespace tehmm {
 
+// ---- diagnostic cycle stamps (only in the -DTEHMM_STAMPS build; never in the product library)
+#ifdef TEHMM_STAMPS
+__device__ unsigned long long g_stamps[4096 * 16];
+__device__ __forceinline__ unsigned long long stamp_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define ST_DECL unsigned long long st_a = 0, st_b = 0, st_c = 0, st_t0 = 0, st_t1 = 0
+#define ST_BEGIN st_t0 = stamp_now()
+#define ST_ADD(acc) do { st_t1 = stamp_now(); acc += st_t1 - st_t0; st_t0 = st_t1; } while (0)
+#define ST_FLUSH(w_)                                                                        \
+  do {                                                                                      \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) {                                     \
+      g_stamps[(blockIdx.x * 4 + (w_)) * 4 + 0] = st_a;                                     \
+      g_stamps[(blockIdx.x * 4 + (w_)) * 4 + 1] = st_b;                                     \
+      g_stamps[(blockIdx.x * 4 + (w_)) * 4 + 2] = st_c;                                     \
+    }                                                                                       \
+  } while (0)
+#else
+#define ST_DECL
+#define ST_BEGIN
+#define ST_ADD(acc)
+#define ST_FLUSH(w_)
+#endif
+
 struct EmisTab {
   const uint32_t *obs32;   // [pos][KPW] packed observation rows
   const double *tab;       // [rows][NP] emission log-prob rows
@@ -32,6 +58,10 @@ struct EmisTab {
   int K, KPW, NP;
   int rowbase[TEHMM_MAX_TRACKS];
   int rowcnt[TEHMM_MAX_TRACKS];
+  // cooperative kernels: tracks whose rows are staged in LDS (ldsbase[k] >= 0 = first LDS row)
+  int ldsbase[TEHMM_MAX_TRACKS];
+  int lds_rows;
+  const double *ltab_src;  // [lds_rows][NP] the LDS-resident rows, packed
 };
 
 struct IntervalTab {
@@ -56,6 +86,9 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
   return v;
+}
+__device__ __forceinline__ double pij_safe(const double *pi, int j, int N) {
+  return j < N ? pi[j] : -INFINITY;
 }
 // frexp-style exponent of a non-negative double (0 -> -1022)
 __device__ __forceinline__ int exp_of(double a) {
@@ -312,15 +345,14 @@ __global__ void k_accumulate_obs(int64_t T, int K, int N, int S, const uint8_t *
 //              and if to == 0: c -= lt[0][0]                                  (quirk Q4)
 //   from >= 1: c = (V[t-1][from] + lt[from][to]) + b[t][to]; if ratios and r[t] > 1:
 //              c += lt[to][to]*(r[t]-1);  strict '>' keeps the lowest index on ties (Q5).
-// Traceback pointers: one byte per (t, state), four consecutive t packed per dword:
-//   tb[((pos0 + t) >> 2) * TBW + state] byte (t & 3).
+// Traceback pointers: one byte per (t, state): tb[(pos0 + t) * TBW + state].
 // LDS: lt [N][NP] | ring [PB][64*SPL] | v [2][64*SPL]
 // ------------------------------------------------------------------------------------------
 template <int SPL, bool RATIO, bool FRAME>
 __global__ __launch_bounds__(64) void k_viterbi(IntervalTab iv, EmisTab em, int N, int NP,
                                                 const double *g_lt, const double *g_pi,
                                                 const double *tratios, const double *frame,
-                                                int TBW, uint32_t *tb, int *last_state,
+                                                int TBW, uint8_t *tb, int *last_state,
                                                 double *logprob) {
   extern __shared__ double sm[];
   constexpr int W = TEHMM_WAVE * SPL;
@@ -345,9 +377,6 @@ __global__ __launch_bounds__(64) void k_viterbi(IntervalTab iv, EmisTab em, int 
 
   bool seen = false;
   int cur = 0;
-  uint32_t tbw[SPL];
-#pragma unroll
-  for (int s = 0; s < SPL; ++s) tbw[s] = 0;
 
   for (int64_t t0 = 0; t0 < T; t0 += TEHMM_PB) {
     const int np = (int)min((int64_t)TEHMM_PB, T - t0);
@@ -424,15 +453,7 @@ __global__ __launch_bounds__(64) void k_viterbi(IntervalTab iv, EmisTab em, int 
             }
           }
           if (j < N) vnext[j] = best;
-          tbw[s] |= (uint32_t)arg << ((t & 3) * 8);
-        }
-      }
-      if ((t & 3) == 3 || t == T - 1) {
-#pragma unroll
-        for (int s = 0; s < SPL; ++s) {
-          int j = lane + TEHMM_WAVE * s;
-          if (j < TBW) tb[((p0 + t) >> 2) * TBW + j] = tbw[s];
-          tbw[s] = 0;
+          if (j < N) tb[(p0 + t) * TBW + j] = (uint8_t)arg;
         }
       }
       cur ^= 1;
@@ -456,15 +477,15 @@ __global__ __launch_bounds__(64) void k_viterbi(IntervalTab iv, EmisTab em, int 
   }
 }
 
-__device__ __forceinline__ int tb_get(const uint32_t *tb, int TBW, int64_t gpos, int s) {
-  return (int)((tb[(gpos >> 2) * TBW + s] >> ((gpos & 3) * 8)) & 0xffu);
+__device__ __forceinline__ int tb_get(const uint8_t *tb, int TBW, int64_t gpos, int s) {
+  return (int)tb[gpos * TBW + s];
 }
 
 // Chunk c of an interval covers pointers t in (lo, hi], lo = c*C, hi = min((c+1)*C, T-1), and maps
 // the state at hi to the state at lo.  compose: G[chunk][s_hi] = s_lo for every s_hi.
 __global__ __launch_bounds__(64) void k_tb_compose(IntervalTab iv, const int *chunk_iv,
                                                    const int64_t *chunk0, int N, int NP, int TBW,
-                                                   const uint32_t *tb, uint8_t *G) {
+                                                   const uint8_t *tb, uint8_t *G) {
   const int c = blockIdx.x;
   const int id = chunk_iv[c];
   const int64_t T = iv.len[id], p0 = iv.pos0[id];
@@ -494,7 +515,7 @@ __global__ void k_tb_scan(IntervalTab iv, const int64_t *chunk0, int NP, const u
 }
 // fill: one thread per chunk walks its pointers and writes the int64 path
 __global__ void k_tb_fill(IntervalTab iv, int n_chunks, const int *chunk_iv, const int64_t *chunk0,
-                          int TBW, const uint32_t *tb, const uint8_t *bstate, int64_t *paths) {
+                          int TBW, const uint8_t *tb, const uint8_t *bstate, int64_t *paths) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_chunks) return;
   const int id = chunk_iv[c];
