@@ -39,6 +39,64 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
   return __hiloint2double(hi, lo);
 }
 
+// ---- state-vector broadcast without LDS -------------------------------------------------------
+// The chain wave keeps the state vector with lane = state.  Every lane needs every element each
+// step.  rep_rows() makes, for each 16-lane row R of the wave, a register in which ALL four rows
+// hold row R's 16 values (two v_permlane32_swap + v_permlane16_swap per dword); bcast<F>() then
+// reads element F with a single DPP move (row_newbcast: lane F&15 of the lane's own row), and the
+// forward / backward products fold the broadcast into the FMA itself (v_fmac_f64_dpp).
+template <int NT>
+__device__ __forceinline__ void rep_rows(double v, double (&r)[(NT + 15) / 16]) {
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);   // [0]: rows 0,1,0,1  [1]: 2,3,2,3
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  const auto c = __builtin_amdgcn_permlane16_swap(a[0], a[0], false, false); // [0]: row 0 x4   [1]: row 1 x4
+  const auto d = __builtin_amdgcn_permlane16_swap(b[0], b[0], false, false);
+  r[0] = __hiloint2double((int)d[0], (int)c[0]);
+  if constexpr (NT > 16) r[1] = __hiloint2double((int)d[1], (int)c[1]);
+  if constexpr (NT > 32) {
+    const auto e = __builtin_amdgcn_permlane16_swap(a[1], a[1], false, false);   // row 2 x4, row 3 x4
+    const auto f = __builtin_amdgcn_permlane16_swap(b[1], b[1], false, false);
+    r[2] = __hiloint2double((int)f[0], (int)e[0]);
+    if constexpr (NT > 48) r[3] = __hiloint2double((int)f[1], (int)e[1]);
+  }
+}
+template <int L>
+__device__ __forceinline__ double bcast(double v) {   // lane L (0..15) of the lane's own row
+  return __longlong_as_double(
+      __builtin_amdgcn_mov_dpp(__double_as_longlong(v), 0x150 + L, 0xf, 0xf, true));
+}
+// x[F] = V[F] + ltc[F] for F = 0..NT-1 (compile-time recursion: the DPP control is an immediate)
+template <int F, int NT>
+struct BcastAdd {
+  static __device__ __forceinline__ void run(const double (&r)[(NT + 15) / 16], const double (&ltc)[NT],
+                                             double (&x)[NT]) {
+    x[F] = bcast<F & 15>(r[F >> 4]) + ltc[F];
+    BcastAdd<F + 1, NT>::run(r, ltc, x);
+  }
+};
+template <int NT>
+struct BcastAdd<NT, NT> {
+  static __device__ __forceinline__ void run(const double (&)[(NT + 15) / 16], const double (&)[NT],
+                                             double (&)[NT]) {}
+};
+// s[F & 3] += V[F] * ac[F] with the broadcast folded into the FMA
+template <int F, int NT>
+struct BcastFma {
+  static __device__ __forceinline__ void run(const double (&r)[(NT + 15) / 16], const double (&ac)[NT],
+                                             double (&s)[4]) {
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(s[F & 3])
+                 : "v"(r[F >> 4]), "v"(ac[F]), "n"(F & 15));
+    BcastFma<F + 1, NT>::run(r, ac, s);
+  }
+};
+template <int NT>
+struct BcastFma<NT, NT> {
+  static __device__ __forceinline__ void run(const double (&)[(NT + 15) / 16], const double (&)[NT],
+                                             double (&)[4]) {}
+};
+
 __device__ __forceinline__ int wave_max_i32_dpp(int v) {
   const int ident = (int)0x80000000;
   v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x111, 0xf, 0xf, false));   // row_shr:1
@@ -201,20 +259,21 @@ __device__ __forceinline__ void stage_emis_table(const EmisTab &e, double *ltab,
 //                 x_from = V_{t-1}[from] + lt[from][to]; hoisting "+ b" out of the max is exact
 //                 because fp64 rounding is monotone (the ARG-max is not hoisted: see below).
 //   wave 1      : emission rows of block it;
-//   waves 2, 3  : the exact arg-max of block it-2 (positions split even / odd):
-//                 lane = to, c_from recomputed in the reference's order (V+lt)+b [+ratio term],
+//   waves 2, 3  : the exact arg-max of block it-2 (lane = position, destination states split):
+//                 c_from recomputed in the reference's order (V+lt)+b [+ratio term],
 //                 arg = lowest from with c_from == V_t[to] (== the reference's strict '>' scan).
-// LDS (doubles): bring [3][CPB][RS] | Vring [2][CPB+1][NT] | ltab [lds_rows][NT]
+// LDS (doubles): bring [3][CPB][RS] | Vring [2][CPB+1][VS] | ltab [lds_rows][NT]
 // ------------------------------------------------------------------------------------------
 template <int NT, int CPB, bool RATIO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_vit_coop(IntervalTab iv, EmisTab em, int N, const double *g_lt, const double *g_pi,
-                const double *tratios, uint8_t *tb, int *last_state, double *logprob) {
+void k_vit_coop(IntervalTab iv, EmisTab em, int N, const double *g_lt, const double *g_ltT,
+                const double *g_pi, const double *tratios, uint8_t *tb, int *last_state, double *logprob) {
   extern __shared__ double sm[];
   constexpr int RS = NT + 1;
+  constexpr int VS = NT + 2;   // V row stride: conflict-free per-lane ds_read_b128 in the arg pass
   double *bring = sm;
   double *Vring = bring + 3 * CPB * RS;
-  double *ltab = Vring + 2 * (CPB + 1) * NT;
+  double *ltab = Vring + 2 * (CPB + 1) * VS;
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
   const int id = iv.order[blockIdx.x];
@@ -237,15 +296,16 @@ void k_vit_coop(IntervalTab iv, EmisTab em, int N, const double *g_lt, const dou
     const double ltd = live ? g_lt[jl * NT + jl] : 0.0;
     const double lt00 = g_lt[0];
     const double pij = live ? g_pi[jl] : -INFINITY;
+    const int vslot = lane < NT ? lane : NT + 1;
     double vcur = -INFINITY;
     for (int64_t it = 0; it < nb + 2; ++it) {
       ST_BEGIN;
       const int64_t bn = it - 1;
       if (bn >= 0 && bn < nb) {
         const int np = (int)min((int64_t)CPB, T - bn * CPB);
-        double *Vr = Vring + (bn & 1) * (CPB + 1) * NT;
+        double *Vr = Vring + (bn & 1) * (CPB + 1) * VS;
         const double *br = bring + (bn % 3) * CPB * RS;
-        if (bn > 0 && lane < NT) Vr[lane] = vcur;
+        if (bn > 0) Vr[vslot] = vcur;
         for (int p = 0; p < np; ++p) {
           const int64_t t = bn * CPB + p;
           const double b = br[p * RS + jl];
@@ -256,18 +316,12 @@ void k_vit_coop(IntervalTab iv, EmisTab em, int N, const double *g_lt, const dou
             v = pij + b;
             if (RATIO && r > 1.) v += ltd * (r - 1.);
           } else {
-            __builtin_amdgcn_wave_barrier();
-            lds_cd2 *vp = lds_row(Vr + p * NT);
-            d2v pv[NT / 2];
-#pragma unroll
-            for (int f2 = 0; f2 < NT / 2; ++f2) pv[f2] = vp[f2];   // all broadcast reads in flight
-            // x_from = V[from] + lt[from][to]: NT independent adds, then a max tree
+            // x_from = V[from] + lt[from][to]: V[from] by DPP row broadcast (no LDS on the chain),
+            // NT independent adds, then a max tree
+            double rr[(NT + 15) / 16];
+            rep_rows<NT>(vcur, rr);
             double x[NT];
-#pragma unroll
-            for (int f2 = 0; f2 < NT / 2; ++f2) {
-              x[2 * f2] = pv[f2].x + ltc[2 * f2];
-              x[2 * f2 + 1] = pv[f2].y + ltc[2 * f2 + 1];
-            }
+            BcastAdd<0, NT>::run(rr, ltc, x);
             double c0 = x[0] + b;
             x[0] = -INFINITY;
 #pragma unroll
@@ -284,7 +338,7 @@ void k_vit_coop(IntervalTab iv, EmisTab em, int N, const double *g_lt, const dou
             v = c1 > c0 ? c1 : c0;      // c0 NaN stays (reference: nothing is '>' a NaN best)
           }
           vcur = v;
-          if (lane < NT) Vr[(p + 1) * NT + lane] = v;
+          Vr[(p + 1) * VS + vslot] = v;     // lanes >= NT hold -inf and share the pad slot
         }
       }
       ST_ADD(st_a);
@@ -330,12 +384,12 @@ void k_vit_coop(IntervalTab iv, EmisTab em, int N, const double *g_lt, const dou
     ST_FLUSH(w);
   } else {
     // ============================================================== exact arg-max (block it-2)
-    // lane = to; c_from recomputed in the reference's order (V+lt)+b [+ratio term];
-    // arg = lowest from with c_from == V_t[to] (== the reference's strict '>' ascending scan).
-    double ltc[NT];
-#pragma unroll
-    for (int f = 0; f < NT; ++f) ltc[f] = live ? g_lt[f * NT + jl] : -INFINITY;
-    const double ltd = live ? g_lt[jl * NT + jl] : 0.0;
+    // lane = position; the two waves split the destination states.  For every (position, to):
+    // c_from recomputed in the reference's order (V+lt)+b [+ratio term] with the lt column as
+    // scalar operands; arg = lowest from with c_from == V_t[to] (== the reference's strict '>'
+    // ascending scan, because V_t[to] is the maximum of the c_from).
+    const int half = (N + 1) / 2;
+    const int to_lo = (w - 2) * half, to_hi = min(N, to_lo + half);
     const double lt00 = g_lt[0];
     for (int64_t it = 0; it < nb + 2; ++it) {
       ST_BEGIN;
@@ -346,40 +400,43 @@ void k_vit_coop(IntervalTab iv, EmisTab em, int N, const double *g_lt, const dou
       if (ba >= 0 && ba < nb) {
 #endif
         const int np = (int)min((int64_t)CPB, T - ba * CPB);
-        const double *Vr = Vring + (ba & 1) * (CPB + 1) * NT;
+        const double *Vr = Vring + (ba & 1) * (CPB + 1) * VS;
         const double *br = bring + (ba % 3) * CPB * RS;
-        for (int p = w - 2; p < np; p += 2) {
-          const int64_t t = ba * CPB + p;
-          if (t == 0) continue;
-          lds_cd2 *vp = lds_row(Vr + p * NT);
-          d2v pv[NT / 2];
+        const int pl = lane < np ? lane : 0;
+        const int64_t t = ba * CPB + pl;
+        const bool actp = lane < np && t > 0;
+        lds_cd2 *vp = lds_row(Vr + pl * VS);          // V[t-1][*] of this lane's position
+        d2v pv[NT / 2];
 #pragma unroll
-          for (int f2 = 0; f2 < NT / 2; ++f2) pv[f2] = vp[f2];
-          const double vt = Vr[(p + 1) * NT + jl];
-          const double b = br[p * RS + jl];
+        for (int f2 = 0; f2 < NT / 2; ++f2) pv[f2] = vp[f2];
+        const double *vnext = Vr + (pl + 1) * VS;     // V[t][*]
+        const double *brow = br + pl * RS;
+        double r = 0.0;
+        if (RATIO) r = tratios[p0 + t];
+        const bool rg = RATIO && r > 1.;
+        for (int to = to_lo; to < to_hi; ++to) {
+          const double *lc = g_ltT + to * NT;           // lt[*][to], wave-uniform
+          const double vt = vnext[to];
+          const double b = brow[to];
           double c[NT];
 #pragma unroll
           for (int f2 = 0; f2 < NT / 2; ++f2) {
-            c[2 * f2] = pv[f2].x + ltc[2 * f2];
-            c[2 * f2 + 1] = pv[f2].y + ltc[2 * f2 + 1];
+            c[2 * f2] = (pv[f2].x + lc[2 * f2]) + b;
+            c[2 * f2 + 1] = (pv[f2].y + lc[2 * f2 + 1]) + b;
           }
-#pragma unroll
-          for (int f = 0; f < NT; ++f) c[f] += b;
           if (RATIO) {
-            const double r = tratios[p0 + t];
-            c[0] += ltd * r;
-            if (lane == 0) c[0] -= lt00;
-            if (r > 1.) {
-              const double addr = ltd * (r - 1.);
+            const double ld = lc[to];
+            c[0] += ld * r;
+            if (to == 0) c[0] -= lt00;
+            const double addr = rg ? ld * (r - 1.) : 0.0;   // x + 0.0 == x for the equality below
 #pragma unroll
-              for (int f = 1; f < NT; ++f) c[f] += addr;
-            }
+            for (int f = 1; f < NT; ++f) c[f] += addr;
           }
           int arg = 0;
 #pragma unroll
           for (int f = NT - 1; f >= 1; --f) arg = c[f] == vt ? f : arg;
           arg = c[0] == vt ? 0 : arg;
-          if (live) tb[(p0 + t) * NT + lane] = (uint8_t)arg;
+          if (actp) tb[(p0 + t) * NT + to] = (uint8_t)arg;
         }
       }
       ST_ADD(st_b);
@@ -449,26 +506,17 @@ void k_fb_coop(IntervalTab iv, EmisTab em, int N, const double *g_A, const doubl
           if (t == 0) {
             a = live ? exp(g_pi[jl]) * bh : 0.0;
           } else {
-            __builtin_amdgcn_wave_barrier();
-            lds_cd2 *vp = lds_row(xF + ((t - 1) & 1) * NT);
-            d2v pv[NT / 2];
-#pragma unroll
-            for (int f2 = 0; f2 < NT / 2; ++f2) pv[f2] = vp[f2];
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-            for (int f4 = 0; f4 < NT / 4; ++f4) {
-              s0 = fma(pv[2 * f4].x, ac[4 * f4], s0);
-              s1 = fma(pv[2 * f4].y, ac[4 * f4 + 1], s1);
-              s2 = fma(pv[2 * f4 + 1].x, ac[4 * f4 + 2], s2);
-              s3 = fma(pv[2 * f4 + 1].y, ac[4 * f4 + 3], s3);
-            }
-            const double ssum = (s0 + s1) + (s2 + s3);
+            double rr[(NT + 15) / 16];
+            rep_rows<NT>(a, rr);
+            double sacc[4] = {0.0, 0.0, 0.0, 0.0};
+            asm volatile("s_nop 1" ::: "memory");   // VALU write -> DPP read wait states
+            BcastFma<0, NT>::run(rr, ac, sacc);
+            const double ssum = (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]);
             // lane NT-1 holds sum_i a_{t-1}[i]: its exponent scales this step
             const int e = ((__builtin_amdgcn_readlane(__double2hiint(ssum), NT - 1) >> 20) & 0x7ff) - 1022;
             a = live ? ldexp(ssum * bh, -e) : 0.0;
             Ecum += (double)e;
           }
-          if (lane < NT) xF[(t & 1) * NT + lane] = a;
           if (live) al[t * N + lane] = a;
         }
       }
@@ -485,7 +533,7 @@ void k_fb_coop(IntervalTab iv, EmisTab em, int N, const double *g_A, const doubl
 #pragma unroll
     for (int j = 0; j < NT; ++j) ac[j] = live ? g_A[jl * NT + j] : (lane == NT - 1 ? 1.0 : 0.0);
     double *be = beta + iv.out0[id] * N;
-    double bt = 0.0;
+    double bt = 0.0, wv = 0.0;
     for (int64_t it = 0; it < nb + 1; ++it) {
       ST_BEGIN;
       const int64_t bn = it - 1;
@@ -499,26 +547,17 @@ void k_fb_coop(IntervalTab iv, EmisTab em, int N, const double *g_A, const doubl
           if (u == T - 1) {
             bt = live ? 1.0 : 0.0;
           } else {
-            __builtin_amdgcn_wave_barrier();
-            lds_cd2 *vp = lds_row(xB + ((u + 1) & 1) * NT);
-            d2v pv[NT / 2];
-#pragma unroll
-            for (int f2 = 0; f2 < NT / 2; ++f2) pv[f2] = vp[f2];
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-            for (int f4 = 0; f4 < NT / 4; ++f4) {
-              s0 = fma(ac[4 * f4], pv[2 * f4].x, s0);
-              s1 = fma(ac[4 * f4 + 1], pv[2 * f4].y, s1);
-              s2 = fma(ac[4 * f4 + 2], pv[2 * f4 + 1].x, s2);
-              s3 = fma(ac[4 * f4 + 3], pv[2 * f4 + 1].y, s3);
-            }
-            const double ssum = (s0 + s1) + (s2 + s3);
+            double rr[(NT + 15) / 16];
+            rep_rows<NT>(wv, rr);
+            double sacc[4] = {0.0, 0.0, 0.0, 0.0};
+            asm volatile("s_nop 1" ::: "memory");
+            BcastFma<0, NT>::run(rr, ac, sacc);
+            const double ssum = (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]);
             const int e = ((__builtin_amdgcn_readlane(__double2hiint(ssum), NT - 1) >> 20) & 0x7ff) - 1022;
             bt = live ? ldexp(ssum, -e) : 0.0;
           }
           if (live) be[u * N + lane] = bt;
-          const double wv = live ? bh * bt : 0.0;
-          if (lane < NT) xB[(u & 1) * NT + lane] = wv;
+          wv = live ? bh * bt : 0.0;
         }
       }
       ST_ADD(st_a);

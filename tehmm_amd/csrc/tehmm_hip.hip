@@ -86,7 +86,7 @@ void allow_lds(F *fn, size_t bytes) {
 struct tehmm_model {
   int N = 0, NP = 0, K = 0, S = 0, R = 0;
   double normalize = 1.0;
-  DBuf<double> lt, A, AT, pi, tab, ltab;
+  DBuf<double> lt, ltT, A, AT, pi, tab, ltab;
   int rowbase[TEHMM_MAX_TRACKS];
   int rowcnt[TEHMM_MAX_TRACKS];
   int ldsbase[TEHMM_MAX_TRACKS];
@@ -332,7 +332,11 @@ int tehmm_model_create(int N, int K, int S, const double *lt, const double *pi,
       for (int s = 0; s < m->rowcnt[k]; ++s)
         for (int j = 0; j < NP; ++j)
           hltab[(size_t)(m->ldsbase[k] + s) * NP + j] = htab[(size_t)(m->rowbase[k] + s) * NP + j];
+  std::vector<double> hltT((size_t)NP * NP, -INFINITY);
+  for (int i = 0; i < NP; ++i)
+    for (int j = 0; j < NP; ++j) hltT[(size_t)j * NP + i] = hlt[(size_t)i * NP + j];
   hipError_t e = m->lt.upload(hlt.data(), hlt.size());
+  if (e == hipSuccess) e = m->ltT.upload(hltT.data(), hltT.size());
   if (e == hipSuccess) e = m->ltab.upload(hltab.data(), hltab.size());
   if (e == hipSuccess) e = m->A.upload(hA.data(), hA.size());
   if (e == hipSuccess) e = m->AT.upload(hAT.data(), hAT.size());
@@ -544,15 +548,15 @@ template <int NT>
 static void launch_vit_coop(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv,
                             const EmisTab &em, bool ratio, hipStream_t st) {
   constexpr int CPB = NT <= 44 ? 64 : 32;
-  size_t lds = ((size_t)3 * CPB * (NT + 1) + 2 * (CPB + 1) * NT + (size_t)m->lds_rows * NT) * sizeof(double);
+  size_t lds = ((size_t)3 * CPB * (NT + 1) + 2 * (CPB + 1) * (NT + 2) + (size_t)m->lds_rows * NT) * sizeof(double);
   if (ratio) {
     allow_lds(k_vit_coop<NT, CPB, true>, lds);
     hipLaunchKernelGGL((k_vit_coop<NT, CPB, true>), dim3(b->n), dim3(256), lds, st, iv, em, m->N,
-                       m->lt.p, m->pi.p, b->ratios.p, b->tb.p, b->last_state.p, b->vit_lp.p);
+                       m->lt.p, m->ltT.p, m->pi.p, b->ratios.p, b->tb.p, b->last_state.p, b->vit_lp.p);
   } else {
     allow_lds(k_vit_coop<NT, CPB, false>, lds);
     hipLaunchKernelGGL((k_vit_coop<NT, CPB, false>), dim3(b->n), dim3(256), lds, st, iv, em, m->N,
-                       m->lt.p, m->pi.p, (const double *)nullptr, b->tb.p, b->last_state.p,
+                       m->lt.p, m->ltT.p, m->pi.p, (const double *)nullptr, b->tb.p, b->last_state.p,
                        b->vit_lp.p);
   }
 }
