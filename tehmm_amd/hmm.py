@@ -1,0 +1,450 @@
+"""MultitrackHmm -- host-side mirror of the reference's ``hmm.py`` model API, with the hot path on
+the MI355X.
+
+Same class / method names and semantics as the reference (train, viterbi, posteriorDecode,
+posteriorDistribution, emissionDistribution, decode, score_samples, fit and the six BaseHMM hooks);
+zeros in the transition / start tables become -1e100 via myLog (hmm.py:625-666, quirk Q1).
+
+Device routing
+  * the hook methods (_do_viterbi_pass, _do_forward_pass, _do_backward_pass,
+    _compute_log_likelihood, _accumulate_sufficient_statistics) call the array-level C-ABI entry
+    points, one-to-one with the Cython functions they replace;
+  * decode / score_samples and the per-TrackData batch methods (viterbi, posteriorDistribution)
+    call the fused entry point tehmm_eval_batch: emission fused into the DP, all tables of a
+    TrackData evaluated in ONE launch, results bit-identical (paths) / within 1e-6 (posteriors).
+There is no CPU fallback: without the HIP library every call raises.
+"""
+import copy
+import string
+
+import numpy as np
+
+from . import _hmm
+from .basehmm import BaseHMM, check_random_state
+from .common import EPSILON, F32_EPS, logger, logsumexp, myLog, normalize
+from .track import TrackTable
+
+
+class MultitrackHmm(BaseHMM):
+    def __init__(self, emissionModel=None, startprob=None, transmat=None, startprob_prior=None,
+                 transmat_prior=None, algorithm="viterbi", random_state=None, n_iter=10, thresh=1e-2,
+                 params=string.ascii_letters, init_params=string.ascii_letters, state_name_map=None,
+                 fudge=0.0, fixTrans=False, fixEmission=False, fixStart=True, forceUserTrans=None,
+                 forceUserEmissions=None, forceUserStart=None, transMatEpsilons=False, maxProb=False,
+                 maxProbCut=None):
+        n_components = emissionModel.getNumStates() if emissionModel is not None else 1
+        # (the reference sets this after BaseHMM.__init__, which breaks zero-containing transmat
+        # arguments -- quirk Q20; here it simply works)
+        self.transMatEpsilons = transMatEpsilons
+        self._dev = None
+        BaseHMM.__init__(self, n_components=n_components, startprob=startprob, transmat=transmat,
+                         startprob_prior=startprob_prior, transmat_prior=transmat_prior,
+                         algorithm=algorithm, random_state=random_state, n_iter=n_iter, thresh=thresh,
+                         params=params, init_params=init_params)
+        self.init_params = init_params
+        self.emissionModel = emissionModel
+        self.trackList = None
+        self.stateNameMap = state_name_map
+        self.fudge = fudge
+        self.fixTrans = fixTrans
+        self.fixEmission = fixEmission
+        self.fixStart = fixStart
+        self.current_iteration = None
+        self.last_forward_log_prob = None
+        self.last_forward_log_prob_it = -1
+        if forceUserTrans is not None or forceUserEmissions is not None or forceUserStart is not None:
+            raise NotImplementedError("forceUser{Trans,Emissions,Start} text files are outside the "
+                                      "hot path this package replaces")
+        self.forceUserTrans = self.forceUserEmissions = self.forceUserStart = None
+        self.maxProb = maxProb
+        self.best_forward_log_prob = None
+        self.bestCopy = None
+        self.maxProbCut = maxProbCut
+        self.numZeroInitEdges = 0
+        self.numZeroInitStarts = 0
+
+    # ------------------------------------------------------------------ public API (hmm.py:155-277)
+    def train(self, trackData):
+        """Unsupervised Baum-Welch from the tables of a TrackData (hmm.py:155-172)."""
+        self.bestCopy = None
+        self.trackList = trackData.getTrackList()
+        self.fit(trackData.getTrackTableList())
+        if self.maxProb is True:
+            assert self.bestCopy is not None
+            self.emissionModel = self.bestCopy.emissionModel
+            self.transmat_ = self.bestCopy.transmat_
+            self._log_transmat = self.bestCopy._log_transmat
+            self.startprob_ = self.bestCopy.startprob_
+            self.last_forward_log_prob = self.bestCopy.last_forward_log_prob
+            self.last_forward_log_prob_it = self.bestCopy.last_forward_log_prob_it
+        self.validate()
+
+    def viterbi(self, trackData, numThreads=1):
+        """(logprob, states) per table (hmm.py:221-237) -- all tables in one fused launch."""
+        assert numThreads == 1
+        tables = trackData.getTrackTableList()
+        if self._algorithm == "map":
+            out = [self.decode(t) for t in tables]
+        else:
+            res = self._eval_tables(tables, viterbi=True, posterior=False)
+            out = list(zip(res["viterbi_logprob"], res["paths"]))
+        return [(p, self._name_states(s)) for p, s in out]
+
+    def posteriorDecode(self, trackData, numThreads=1):
+        """hmm.py:239-252: decode(algorithm="map") -- which still runs Viterbi unless the model itself
+        was built with algorithm="map" (quirk Q14)."""
+        if self._algorithm == "map":
+            return [(p, self._name_states(s))
+                    for p, s in (self.decode(t, algorithm="map") for t in trackData.getTrackTableList())]
+        return self.viterbi(trackData, numThreads)
+
+    def posteriorDistribution(self, trackData):
+        """Posterior [T, N] per table (hmm.py:254-263) -- all tables in one fused launch."""
+        res = self._eval_tables(trackData.getTrackTableList(), viterbi=False, posterior=True)
+        return res["posteriors"]
+
+    def emissionDistribution(self, trackData):
+        return [self._compute_log_likelihood(t) for t in trackData.getTrackTableList()]
+
+    def getTrackList(self):
+        return self.trackList
+
+    def getStateNameMap(self):
+        return self.stateNameMap
+
+    def getEmissionModel(self):
+        return self.emissionModel
+
+    def getTransitionProbs(self):
+        return self.transmat_
+
+    def getStartProbs(self):
+        return self.startprob_
+
+    def validate(self):
+        assert len(self.startprob_) == self.emissionModel.getNumStates()
+        assert not np.isnan(self.startprob_.any())
+        assert not np.isnan(self.transmat_.any())
+        assert len(self.transmat_) == self.emissionModel.getNumStates()
+        np.testing.assert_array_almost_equal(np.sum(self.startprob_), 1.)
+        for i in range(len(self.transmat_)):
+            np.testing.assert_array_almost_equal(np.sum(self.transmat_[i]), 1.0)
+        self.emissionModel.validate()
+
+    # ------------------------------------------------------------------ fused device paths
+    def _device_model(self):
+        """HipModel for the current parameters (rebuilt when any table changed)."""
+        from .engine import HipModel
+        em = self.emissionModel
+        key = (self._log_transmat.tobytes(), self._log_startprob.tobytes(), em.logProbs.tobytes(),
+               float(em.normalizeFac))
+        if self._dev is None or self._dev[0] != key:
+            self._dev = (key, HipModel(self._log_transmat, self._log_startprob, em.logProbs,
+                                       normalize=em.normalizeFac,
+                                       symbols_per_track=em.getNumSymbolsPerTrack()))
+        return self._dev[1]
+
+    def _can_fuse(self, tables):
+        from . import _lib
+        if self.n_components > _lib.load().tehmm_max_states():
+            return False
+        for t in tables:
+            a = t.getNumPyArray() if isinstance(t, TrackTable) else t
+            if not (isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.ndim == 2):
+                return False
+        return True
+
+    def _eval_tables(self, tables, viterbi, posterior):
+        """decode and/or score_samples over a list of tables.  Ratio semantics exactly as the
+        reference drivers: emission never sees ratios; Viterbi transitions do (Q11); posteriors
+        never (Q12)."""
+        if not self._can_fuse(tables):
+            out = {"viterbi_logprob": [], "paths": [], "forward_logprob": [], "posteriors": []}
+            for t in tables:
+                if viterbi:
+                    lp, s = self._decode_viterbi(t)
+                    out["viterbi_logprob"].append(lp)
+                    out["paths"].append(s)
+                if posterior:
+                    lp, p = BaseHMM.score_samples(self, t)
+                    out["forward_logprob"].append(lp)
+                    out["posteriors"].append(p)
+            return out
+        from .engine import HipBatch
+        arrays = [t.getNumPyArray() if isinstance(t, TrackTable) else np.ascontiguousarray(t)
+                  for t in tables]
+        lens = np.asarray([a.shape[0] for a in arrays], dtype=np.int64)
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        ratios = [self.emissionModel.getSegmentRatios(t) for t in tables]
+        use_ratios = viterbi and any(r is not None for r in ratios)
+        rcat = None
+        if use_ratios:
+            # a table without ratios behaves like ratio 1.0 on transitions only if the reference
+            # would skip every ratio branch; keep exactness by evaluating such tables separately
+            if any(r is None for r in ratios):
+                res_a = self._eval_tables([t for t, r in zip(tables, ratios) if r is not None],
+                                          viterbi, posterior)
+                res_b = self._eval_tables([t for t, r in zip(tables, ratios) if r is None],
+                                          viterbi, posterior)
+                return _merge_results(res_a, res_b, [r is not None for r in ratios])
+            rcat = np.concatenate(ratios)
+        obs = np.concatenate(arrays, axis=0) if len(arrays) > 1 else arrays[0]
+        hm = self._device_model()
+        hb = HipBatch(obs, offs, rcat)
+        res = hm.eval(hb, viterbi=viterbi, posterior=posterior, use_ratios=use_ratios)
+        out = dict(res)
+        if viterbi:
+            p = hb.paths()
+            out["paths"] = [p[offs[i]:offs[i + 1]] for i in range(len(lens))]
+        if posterior:
+            q = hb.posteriors()
+            out["posteriors"] = [q[offs[i]:offs[i + 1]] for i in range(len(lens))]
+        hb.close()
+        return out
+
+    def decode(self, obs, algorithm="viterbi"):
+        """BaseHMM.decode (basehmm.py:361-396), fused on the device for the Viterbi case."""
+        if self._algorithm in ("viterbi", "map"):
+            algorithm = self._algorithm
+        if algorithm == "viterbi" and self._can_fuse([obs]):
+            res = self._eval_tables([obs], viterbi=True, posterior=False)
+            return res["viterbi_logprob"][0], res["paths"][0]
+        return BaseHMM.decode(self, obs, algorithm)
+
+    def score_samples(self, obs):
+        """BaseHMM.score_samples (basehmm.py:238-273), fused on the device."""
+        if self._can_fuse([obs]):
+            res = self._eval_tables([obs], viterbi=False, posterior=True)
+            lp = res["forward_logprob"][0]
+            self._note_forward_logprob(lp)
+            return lp, res["posteriors"][0]
+        return BaseHMM.score_samples(self, obs)
+
+    def _name_states(self, states):
+        if self.stateNameMap is None:
+            return states
+        names = np.asarray([self.stateNameMap.getMapBack(i) for i in range(self.n_components)],
+                           dtype=object)
+        return list(names[np.asarray(states)])
+
+    # ------------------------------------------------------------------ BaseHMM overrides (hmm.py:524-729)
+    def _compute_log_likelihood(self, obs):
+        return self.emissionModel.allLogProbs(obs)
+
+    def _generate_sample_from_state(self, state, random_state=None):
+        return None
+
+    def _init(self, obs, params='ste'):
+        if self.fixTrans is True:
+            self.params = self.params.replace("t", "")
+        if self.fixEmission is True:
+            self.params = self.params.replace("e", "")
+        if self.fixStart is True:
+            self.params = self.params.replace("s", "")
+        super(MultitrackHmm, self)._init(obs, params=params)
+        self.random_state = check_random_state(self.random_state)
+
+    def _initialize_sufficient_statistics(self):
+        stats = super(MultitrackHmm, self)._initialize_sufficient_statistics()
+        stats['obs'] = self.emissionModel.initStats()
+        return stats
+
+    def _accumulate_sufficient_statistics(self, stats, obs, framelogprob, posteriors, fwdlattice,
+                                          bwdlattice, params):
+        """hmm.py:545-574."""
+        stats['nobs'] += 1
+        if 's' in params:
+            stats['start'] += posteriors[0]
+        if 't' in params:
+            n_observations, n_components = framelogprob.shape
+            if n_observations > 1:
+                logsum_lneta = np.zeros((n_components, n_components))
+                lnP = logsumexp(fwdlattice[-1])
+                _hmm._log_sum_lneta(n_observations, n_components, fwdlattice, self._log_transmat,
+                                    bwdlattice, framelogprob, lnP,
+                                    self.emissionModel.getSegmentRatios(obs), logsum_lneta)
+                stats["trans"] += np.exp(logsum_lneta)
+        if 'e' in params:
+            self.emissionModel.accumulateStats(obs, stats['obs'], posteriors)
+
+    def _do_estep(self, obs, stats):
+        """E-step over all sequences.  When every sequence is a uint8 table the fused device entry
+        point (tehmm_estep_batch) does the whole loop of basehmm.py:507-522 in one call."""
+        from . import _lib
+        if self._can_fuse(obs) and _fused_estep_available():
+            return self._fused_estep(obs, stats)
+        return BaseHMM._do_estep(self, obs, stats)
+
+    def _fused_estep(self, tables, stats):
+        from .engine import HipBatch
+        arrays = [t.getNumPyArray() if isinstance(t, TrackTable) else np.ascontiguousarray(t)
+                  for t in tables]
+        ratios = [self.emissionModel.getSegmentRatios(t) for t in tables]
+        groups = {True: [i for i, r in enumerate(ratios) if r is not None],
+                  False: [i for i, r in enumerate(ratios) if r is None]}
+        hm = self._device_model()
+        N = self.n_components
+        start = np.zeros(N)
+        trans = np.zeros((N, N))
+        obs_stats = np.zeros_like(stats['obs'])
+        total_lp = 0.0
+        for has_r, idx in groups.items():
+            if not idx:
+                continue
+            lens = np.asarray([arrays[i].shape[0] for i in idx], dtype=np.int64)
+            offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            obs = np.concatenate([arrays[i] for i in idx], axis=0)
+            rcat = np.concatenate([ratios[i] for i in idx]) if has_r else None
+            hb = HipBatch(obs, offs, rcat)
+            total_lp += hm.estep(hb, has_r, start, trans, obs_stats)
+            hb.close()
+        stats['nobs'] += len(tables)
+        if 's' in self.params:
+            stats['start'] += start
+        if 't' in self.params:
+            stats['trans'] += trans
+        if 'e' in self.params:
+            stats['obs'] += obs_stats
+        self._note_forward_logprob(total_lp, whole_iteration=True)
+        return total_lp
+
+    def _do_mstep(self, stats, params):
+        """hmm.py:576-616."""
+        self.validate()
+        if self.startprob_prior is None:
+            self.startprob_prior = 1.0
+        if self.transmat_prior is None:
+            self.transmat_prior = 1.0
+        if 's' in params:
+            self.startprob_ = normalize(np.maximum(self.startprob_prior - 1.0 + stats['start'], 1e-20))
+        if 't' in params:
+            lastMat = copy.deepcopy(self.transmat_)
+            transmat_ = self.transmat_prior - 1.0 + stats['trans']
+            for row in range(len(transmat_)):
+                rowSum = np.sum(transmat_[row])
+                if rowSum < EPSILON:
+                    transmat_[row] = lastMat[row]          # orphaned state keeps its old row
+                else:
+                    transmat_[row] = transmat_[row] / rowSum
+            self.transmat_ = transmat_
+        if 'e' in params:
+            self.emissionModel.maximize(stats['obs'], self.trackList)
+        self.current_iteration += 1
+        self.validate()
+
+    def fit(self, obs, **kwargs):
+        self.current_iteration = 1
+        return BaseHMM.fit(self, obs, **kwargs)
+
+    # transmat / startprob keep exact zeros (-> -1e100), hmm.py:622-666
+    def _get_transmat(self):
+        return np.exp(self._log_transmat)
+
+    def _set_transmat(self, transmat):
+        if transmat is None:
+            transmat = np.tile(1.0 / self.n_components, (self.n_components, self.n_components))
+        transmat = np.asarray(transmat, dtype=np.float64)
+        if not np.all(transmat) and self.transMatEpsilons is True:
+            transmat = normalize(transmat.copy(), axis=1)
+        if transmat.shape != (self.n_components, self.n_components):
+            raise ValueError('transmat must have shape (n_components, n_components)')
+        if not np.all(np.allclose(np.sum(transmat, axis=1), 1.0)):
+            raise ValueError('Rows of transmat must sum to 1.0')
+        self._log_transmat = np.asarray(myLog(transmat.copy()), dtype=np.float64)
+
+    transmat_ = property(_get_transmat, _set_transmat)
+
+    def _get_startprob(self):
+        return np.exp(self._log_startprob)
+
+    def _set_startprob(self, startprob):
+        if startprob is None:
+            startprob = np.tile(1.0 / self.n_components, self.n_components)
+        else:
+            startprob = np.asarray(startprob, dtype=np.float64)
+        if len(startprob) != self.n_components:
+            raise ValueError('startprob must have length n_components')
+        if not np.allclose(np.sum(startprob), 1.0):
+            raise ValueError('startprob must sum to 1.0')
+        self._log_startprob = np.asarray(myLog(np.asarray(startprob).copy()), dtype=np.float64)
+
+    startprob_ = property(_get_startprob, _set_startprob)
+
+    def _do_viterbi_pass(self, framelogprob, obs=None):
+        n_observations, n_components = framelogprob.shape
+        state_sequence, logprob = _hmm._viterbi(
+            n_observations, n_components, self._log_startprob, self._log_transmat,
+            self.emissionModel.getSegmentRatios(obs), np.ascontiguousarray(framelogprob))
+        return logprob, state_sequence
+
+    def _note_forward_logprob(self, lp, whole_iteration=False):
+        """EM best-iteration bookkeeping of hmm.py:690-711 (quirk Q17)."""
+        if self.last_forward_log_prob_it != self.current_iteration or whole_iteration:
+            if self.maxProb is True and (self.current_iteration == 1 or (
+                    self.best_forward_log_prob is not None
+                    and self.last_forward_log_prob > self.best_forward_log_prob)):
+                self.best_forward_log_prob = self.last_forward_log_prob
+                dev, self._dev = self._dev, None
+                self.bestCopy = copy.deepcopy(self)
+                self._dev = dev
+            self.last_forward_log_prob = lp
+            self.last_forward_log_prob_it = self.current_iteration
+            if (self.maxProb is True and self.bestCopy is not None and self.maxProbCut is not None
+                    and self.current_iteration - self.bestCopy.current_iteration > self.maxProbCut):
+                logger.info("Stopping due to --maxProbCut %d" % self.maxProbCut)
+                self.n_iter = self.current_iteration
+        else:
+            self.last_forward_log_prob += lp
+            if self.maxProb is True and self.current_iteration > 1 and \
+                    self.last_forward_log_prob > self.best_forward_log_prob:
+                self.best_forward_log_prob = self.last_forward_log_prob
+                dev, self._dev = self._dev, None
+                self.bestCopy = copy.deepcopy(self)
+                self._dev = dev
+
+    def _do_forward_pass(self, framelogprob, obs=None):
+        n_observations, n_components = framelogprob.shape
+        fwdlattice = np.zeros((n_observations, n_components))
+        _hmm._forward(n_observations, n_components, self._log_startprob, self._log_transmat,
+                      np.ascontiguousarray(framelogprob), self.emissionModel.getSegmentRatios(obs),
+                      fwdlattice)
+        lp = logsumexp(fwdlattice[-1])
+        self._note_forward_logprob(lp)
+        return lp, fwdlattice
+
+    def _do_backward_pass(self, framelogprob, obs=None):
+        n_observations, n_components = framelogprob.shape
+        bwdlattice = np.zeros((n_observations, n_components))
+        _hmm._backward(n_observations, n_components, self._log_startprob, self._log_transmat,
+                       np.ascontiguousarray(framelogprob), self.emissionModel.getSegmentRatios(obs),
+                       bwdlattice)
+        return bwdlattice
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_dev"] = None            # device handles are not picklable / copyable
+        return d
+
+
+def _fused_estep_available():
+    return False
+
+
+def _merge_results(res_a, res_b, mask):
+    out = {}
+    for k in set(res_a) | set(res_b):
+        a, b = res_a.get(k), res_b.get(k)
+        if a is None or b is None:
+            out[k] = None
+            continue
+        ia = ib = 0
+        merged = []
+        for m in mask:
+            if m:
+                merged.append(a[ia])
+                ia += 1
+            else:
+                merged.append(b[ib])
+                ib += 1
+        out[k] = np.asarray(merged) if k.endswith("logprob") else merged
+    return out

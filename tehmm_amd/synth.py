@@ -4,7 +4,7 @@ This is the generator SURVEY.md section 8(d) describes: sticky random transition
 uniform start, per-track multinomial rows (symbol 0 = "missing", log-prob 0 as in
 emission.py:155-159) and 250-bin gaussian tracks baked into the same table
 (emission.py:552-584).  Used by the tests, by tests/golden/make_golden.py and by bench.py.
-Nothing here touches the GPU or the oracle.
+Nothing here touches the GPU or the CPU checker.
 """
 from dataclasses import dataclass
 from typing import List, Optional, Sequence

@@ -96,3 +96,77 @@ class IntegerTrackTable(TrackTable):
         assert data.ndim == 2 and data.shape[1] == self.numTracks
         self.data = data
         return self
+
+
+class IdentityValueMap(object):
+    """Value map of a numeric (binned) track: symbol s (1-based, 0 = missing) <-> value s - 1.
+    Stands in for CategoryMap (track.py:668-760) where only getMapBack is needed (the gaussian
+    re-fit of the M-step, emission.py:520-545)."""
+
+    def __init__(self, scale=1.0, shift=0.0):
+        self.scale = float(scale)
+        self.shift = float(shift)
+
+    def getMapBack(self, symbol):
+        return (float(symbol) - 1.0) * self.scale + self.shift
+
+    def getMap(self, value, update=False):
+        return int(round((float(value) - self.shift) / self.scale)) + 1
+
+
+class Track(object):
+    """The per-track metadata the hot path's callers look at (track.py:27-99)."""
+
+    def __init__(self, name, number, dist="multinomial", valueMap=None):
+        self.name = name
+        self.number = number
+        self.dist = dist
+        self.valueMap = valueMap if valueMap is not None else IdentityValueMap()
+
+    def getName(self):
+        return self.name
+
+    def getNumber(self):
+        return self.number
+
+    def getDist(self):
+        return self.dist
+
+    def getValueMap(self):
+        return self.valueMap
+
+
+class TrackList(list):
+    def getTrackByNumber(self, n):
+        return self[n]
+
+    def getTrackByName(self, name):
+        for t in self:
+            if t.getName() == name:
+                return t
+        return None
+
+
+class TrackData(object):
+    """Container of the TrackTables of a set of intervals (track.py:838-977 without the BED / XML
+    loading, which stays outside the hot path)."""
+
+    def __init__(self, trackTableList=None, trackList=None, numSymbolsPerTrack=None):
+        self.trackTableList = list(trackTableList) if trackTableList is not None else []
+        self.trackList = trackList
+        self.numSymbolsPerTrack = numSymbolsPerTrack
+
+    def getTrackTableList(self):
+        return self.trackTableList
+
+    def getTrackList(self):
+        return self.trackList
+
+    def getNumTracks(self):
+        return self.trackTableList[0].getNumTracks() if self.trackTableList else 0
+
+    def getNumTrackTables(self):
+        return len(self.trackTableList)
+
+    def getNumSymbolsPerTrack(self):
+        return self.numSymbolsPerTrack
