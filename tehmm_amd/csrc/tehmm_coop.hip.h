@@ -461,7 +461,7 @@ template <int NT, int CPB, bool TRATIO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_fb_coop(IntervalTab iv, EmisTab em, int N, const double *g_A, const double *g_lt,
                const double *g_pi, const double *tratios, double *alpha, double *beta,
-               double *fwd_logprob, int *dead_flag) {
+               double *fwd_logprob, int *dead_flag, double *wrows, int *escale) {
   extern __shared__ double sm[];
   constexpr int RS = NT + 1;
   double *ringF = sm;
@@ -491,6 +491,7 @@ void k_fb_coop(IntervalTab iv, EmisTab em, int N, const double *g_A, const doubl
 #pragma unroll
     for (int i = 0; i < NT; ++i) ac[i] = live ? g_A[i * NT + jl] : (lane == NT - 1 ? 1.0 : 0.0);
     double *al = alpha + iv.out0[id] * N;
+    int *es = escale ? escale + iv.out0[id] : nullptr;     // E-step: exponent applied at each step
     double Ecum = 0.0, Mcum = 0.0, a = 0.0;
     for (int64_t it = 0; it < nb + 1; ++it) {
       ST_BEGIN;
@@ -516,6 +517,7 @@ void k_fb_coop(IntervalTab iv, EmisTab em, int N, const double *g_A, const doubl
             const int e = ((__builtin_amdgcn_readlane(__double2hiint(ssum), NT - 1) >> 20) & 0x7ff) - 1022;
             a = live ? ldexp(ssum * bh, -e) : 0.0;
             Ecum += (double)e;
+            if (es && lane == 0) es[t] = e;
           }
           if (live) al[t * N + lane] = a;
         }
@@ -533,6 +535,7 @@ void k_fb_coop(IntervalTab iv, EmisTab em, int N, const double *g_A, const doubl
 #pragma unroll
     for (int j = 0; j < NT; ++j) ac[j] = live ? g_A[jl * NT + j] : (lane == NT - 1 ? 1.0 : 0.0);
     double *be = beta + iv.out0[id] * N;
+    double *wr = wrows ? wrows + iv.out0[id] * N : nullptr;   // E-step: w_u = bh'_u * beta_u rows
     double bt = 0.0, wv = 0.0;
     for (int64_t it = 0; it < nb + 1; ++it) {
       ST_BEGIN;
@@ -558,6 +561,7 @@ void k_fb_coop(IntervalTab iv, EmisTab em, int N, const double *g_A, const doubl
           }
           if (live) be[u * N + lane] = bt;
           wv = live ? bh * bt : 0.0;
+          if (wr && live) wr[u * N + lane] = wv;
         }
       }
       ST_ADD(st_a);
@@ -631,6 +635,106 @@ __global__ __launch_bounds__(256) void k_combine(int64_t rows, int N, double *al
     }
   }
 }
+// ------------------------------------------------------------------------------------------
+// Baum-Welch E-step accumulation (basehmm.py:516-522 + hmm.py:545-574 + _hmm.pyx:62-117 +
+// _emission.pyx:165-190 in the scaled linear domain), parallel over position chunks.
+// With a_t, beta_t the scaled rows of k_fb_coop, w_t = bh'_t * beta_t, e_t the power-of-two exponent
+// applied at forward step t and G_t = sum_j a_t[j] beta_t[j]:
+//   gamma_t = a_t * beta_t / G_t                                  (posterior, no eps: fit)
+//   xi_t(i,j) = a_t[i] A[i][j] w_{t+1}[j] / (2^{e_{t+1}} G_{t+1})   (sums to 1 over i,j)
+//   trans    += (1/N) * ( A o sum_t a_t (x) w_{t+1}/Z_t  +  diag( sum_{r_{t+1}>1} (r_{t+1}-1) gamma_{t+1} ) )
+//               (the 1/N is the reference's log(1/N) backward terminal, quirk Q3; the diagonal
+//                term is its extra `y` term for segment ratios, _hmm.pyx:94-99)
+//   obs[k][j][sym] += gamma_t[j] * r_t ;  start += gamma_0.
+// One wave per chunk of CH positions, lane = state j, C[i][lane] in registers, a_{t-1}[i] as
+// scalar operands.  Small tracks' histograms are privatised in LDS, the others use fp64 global
+// atomics.  C, D, start, the histograms are summed into global accumulators with atomics.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_f64_all(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <int NT, bool RATIO>
+__global__ __launch_bounds__(256) void k_estep_accum(IntervalTab iv, EmisTab em, int N, int chunk_len,
+                                                     const int *chunk_iv, const int64_t *chunk_t0,
+                                                     int n_chunks, const double *alpha,
+                                                     const double *beta, const double *wrows,
+                                                     const int *escale, double *gC, double *gD,
+                                                     double *gstart, double *gstat) {
+  extern __shared__ double sm[];
+  double *lstat = sm;                       // [lds_rows][NT] privatised histogram of the small tracks
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < em.lds_rows * NT; i += 256) lstat[i] = 0.0;
+  __syncthreads();
+  const bool live = lane < N;
+  const int c = blockIdx.x * 4 + w;
+  if (c < n_chunks) {
+    const int id = chunk_iv[c];
+    const int64_t T = iv.len[id];
+    const int64_t p0 = iv.pos0[id];
+    const int64_t r0 = iv.out0[id];
+    const int64_t tlo = chunk_t0[c];
+    const int64_t thi = min(T, tlo + chunk_len);
+    double C[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) C[i] = 0.0;
+    double D = 0.0;
+    for (int64_t t = tlo; t < thi; ++t) {
+      const int64_t row = r0 + t;
+      const double a = live ? alpha[row * N + lane] : 0.0;
+      const double b = live ? beta[row * N + lane] : 0.0;
+      const double g = a * b;
+      const double G = wave_sum_f64_all(g);
+      const double invG = 1.0 / G;
+      double gam = g * invG;
+      double r = 1.0;
+      if (RATIO) r = em.ratios[p0 + t];
+      if (t == 0 && live) atomicAdd(&gstart[lane], gam);
+      // ---- transition statistics for the pair (t-1, t)
+      if (t > 0) {
+        const double wv = live ? wrows[row * N + lane] : 0.0;
+        const double wz = wv * ldexp(invG, -escale[row]);
+        const double *ap = alpha + (row - 1) * N;          // a_{t-1}[*]: wave-uniform, scalar loads
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+          if (i < N) C[i] = fma(ap[i], wz, C[i]);
+        if (RATIO && r > 1.) D += (r - 1.) * gam;
+      }
+      // ---- emission statistics
+      const double gr = RATIO ? gam * r : gam;
+      const uint32_t *orow = em.obs32 + (p0 + t) * em.KPW;
+      for (int k = 0; k < em.K; ++k) {
+        int sym = (int)((orow[k >> 2] >> ((k & 3) * 8)) & 0xffu);
+        sym = min(sym, em.rowcnt[k] - 1);
+        const int lb = em.ldsbase[k];
+        if (live) {
+          if (lb >= 0) atomicAdd(&lstat[(lb + sym) * NT + lane], gr);
+          else atomicAdd(&gstat[(int64_t)(em.rowbase[k] + sym) * NT + lane], gr);
+        }
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+        if (i < N) atomicAdd(&gC[i * NT + lane], C[i]);
+      if (RATIO) atomicAdd(&gD[lane], D);
+    }
+  }
+  __syncthreads();
+  // flush the privatised histogram: LDS row (ldsbase[k] + s) -> global row (rowbase[k] + s)
+  for (int k = 0; k < em.K; ++k) {
+    const int lb = em.ldsbase[k];
+    if (lb < 0) continue;
+    for (int i = threadIdx.x; i < em.rowcnt[k] * NT; i += 256) {
+      const double v = lstat[lb * NT + i];
+      if (v != 0.0) atomicAdd(&gstat[(int64_t)em.rowbase[k] * NT + i], v);
+    }
+  }
+}
+
 // intervals whose forward pass met an impossible row after the first emittable one: the
 // reference's lattices are NaN from there on; make the outputs say so.
 __global__ void k_poison_dead(IntervalTab iv, const int *dead_flag, int N, double *post,

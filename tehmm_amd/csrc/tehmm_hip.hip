@@ -569,7 +569,7 @@ static void launch_fb_coop(tehmm_batch *b, const tehmm_model *m, const IntervalT
   allow_lds(k_fb_coop<NT, CPB, false>, lds);
   hipLaunchKernelGGL((k_fb_coop<NT, CPB, false>), dim3(b->n), dim3(256), lds, st, iv, em, m->N, m->A.p,
                      m->lt.p, m->pi.p, (const double *)nullptr, b->post.p, b->beta.p, b->fwd_lp.p,
-                     b->dead.p);
+                     b->dead.p, (double *)nullptr, (int *)nullptr);
 }
 
 #define TEHMM_NT_DISPATCH(NP_, CALL)                                                                \
@@ -780,12 +780,146 @@ int tehmm_viterbi(int64_t T, int N, const double *pi, const double *lt, const do
   return TEHMM_OK;
 }
 
+// ---- fused Baum-Welch E-step ---------------------------------------------------------------
+namespace {
+constexpr int kEstepChunk = 512;
+
+struct EstepWork {
+  DBuf<double> alpha, beta, wrows, fwd_lp, C, D, start, stat;
+  DBuf<int> escale, dead, order, chunk_iv;
+  DBuf<int64_t> grow0, chunk_t0;
+};
+
+template <int NT>
+void launch_estep(const tehmm_model *m, const IntervalTab &iv, const EmisTab &em, bool ratio, int n_iv,
+                  int n_chunks, EstepWork &w, const double *tratios, hipStream_t st) {
+  constexpr int CPB = NT <= 44 ? 64 : 32;
+  size_t lds = ((size_t)4 * CPB * (NT + 1) + 4 * CPB + 5 * NT + (size_t)m->lds_rows * NT) * sizeof(double);
+  size_t lds2 = (size_t)std::max(1, m->lds_rows) * NT * sizeof(double);
+  if (ratio) {
+    allow_lds(k_fb_coop<NT, CPB, true>, lds);
+    hipLaunchKernelGGL((k_fb_coop<NT, CPB, true>), dim3(n_iv), dim3(256), lds, st, iv, em, m->N, m->A.p,
+                       m->lt.p, m->pi.p, tratios, w.alpha.p, w.beta.p, w.fwd_lp.p, w.dead.p, w.wrows.p,
+                       w.escale.p);
+    allow_lds(k_estep_accum<NT, true>, lds2);
+    hipLaunchKernelGGL((k_estep_accum<NT, true>), dim3((n_chunks + 3) / 4), dim3(256), lds2, st, iv, em,
+                       m->N, kEstepChunk, w.chunk_iv.p, w.chunk_t0.p, n_chunks, w.alpha.p, w.beta.p,
+                       w.wrows.p, w.escale.p, w.C.p, w.D.p, w.start.p, w.stat.p);
+  } else {
+    allow_lds(k_fb_coop<NT, CPB, false>, lds);
+    hipLaunchKernelGGL((k_fb_coop<NT, CPB, false>), dim3(n_iv), dim3(256), lds, st, iv, em, m->N, m->A.p,
+                       m->lt.p, m->pi.p, (const double *)nullptr, w.alpha.p, w.beta.p, w.fwd_lp.p,
+                       w.dead.p, w.wrows.p, w.escale.p);
+    allow_lds(k_estep_accum<NT, false>, lds2);
+    hipLaunchKernelGGL((k_estep_accum<NT, false>), dim3((n_chunks + 3) / 4), dim3(256), lds2, st, iv, em,
+                       m->N, kEstepChunk, w.chunk_iv.p, w.chunk_t0.p, n_chunks, w.alpha.p, w.beta.p,
+                       w.wrows.p, w.escale.p, w.C.p, w.D.p, w.start.p, w.stat.p);
+  }
+}
+}  // namespace
+
 int tehmm_estep_batch(tehmm_model_t *m, tehmm_batch_t *b, int use_ratios, double *start,
                       double *trans, double *obsStats, double *logprob_sum) {
-  (void)m; (void)b; (void)use_ratios; (void)start; (void)trans; (void)obsStats; (void)logprob_sum;
-  return fail(TEHMM_ERR_UNSUPPORTED, "tehmm_estep_batch: not built yet");
+  if (!m || !b || !start || !trans || !obsStats || !logprob_sum)
+    return fail(TEHMM_ERR_ARG, "tehmm_estep_batch: NULL argument");
+  if (m->K != b->K) return fail(TEHMM_ERR_ARG, "tehmm_estep_batch: model/batch track count differ");
+  if (m->N >= 64) return fail(TEHMM_ERR_UNSUPPORTED, "tehmm_estep_batch: N >= 64 (use the array-level path)");
+  *logprob_sum = 0.0;
+  if (b->n == 0 || b->total == 0) return TEHMM_OK;
+  const bool ratio = use_ratios && b->has_ratios;
+  const int N = m->N, NP = m->NP, K = m->K, S = m->S;
+  // Intervals are processed in groups whose alpha / beta / w rows fit a fixed workspace
+  // (3 x 8N + 4 bytes per position): the 3 Gb training sets of config 4 never materialise
+  // whole-genome lattices.
+  const int64_t budget_rows = std::max<int64_t>((int64_t)(12ll << 30) / (24 * N + 4), 1);
+  EstepWork w;
+  HIPCHK(w.C.alloc((size_t)NP * NP));
+  HIPCHK(w.D.alloc((size_t)NP));
+  HIPCHK(w.start.alloc((size_t)NP));
+  HIPCHK(w.stat.alloc((size_t)m->R * NP));
+  HIPCHK(hipMemset(w.C.p, 0, (size_t)NP * NP * sizeof(double)));
+  HIPCHK(hipMemset(w.D.p, 0, (size_t)NP * sizeof(double)));
+  HIPCHK(hipMemset(w.start.p, 0, (size_t)NP * sizeof(double)));
+  HIPCHK(hipMemset(w.stat.p, 0, (size_t)m->R * NP * sizeof(double)));
+  IntervalTab iv;
+  EmisTab em;
+  fill_tabs(m, b, iv, em, ratio);     // fit applies the ratios to emissions too (basehmm.py:510)
+  double lp_total = 0.0;
+  int dead_any = 0;
+  size_t pos_in_order = 0;
+  while (pos_in_order < (size_t)b->n) {
+    // next group: consecutive slots of the longest-first order
+    std::vector<int> g_order;
+    std::vector<int64_t> grow0((size_t)b->n, 0);
+    std::vector<int> chunk_iv;
+    std::vector<int64_t> chunk_t0;
+    int64_t rows = 0;
+    while (pos_in_order < (size_t)b->n) {
+      const int id = b->h_order[pos_in_order];
+      const int64_t T = b->h_len[id];
+      if (!g_order.empty() && rows + T > budget_rows) break;
+      g_order.push_back(id);
+      grow0[id] = rows;
+      for (int64_t t0 = 0; t0 < T; t0 += kEstepChunk) {
+        chunk_iv.push_back(id);
+        chunk_t0.push_back(t0);
+      }
+      rows += T;
+      ++pos_in_order;
+    }
+    if (rows == 0) continue;
+    HIPCHK(w.alpha.alloc((size_t)rows * N + 1));
+    HIPCHK(w.beta.alloc((size_t)rows * N + 1));
+    HIPCHK(w.wrows.alloc((size_t)rows * N + 1));
+    HIPCHK(w.escale.alloc((size_t)rows + 1));
+    HIPCHK(w.fwd_lp.alloc((size_t)b->n + 1));
+    HIPCHK(w.dead.alloc((size_t)b->n + 1));
+    HIPCHK(hipMemset(w.dead.p, 0, (size_t)(b->n + 1) * sizeof(int)));
+    HIPCHK(hipMemset(w.escale.p, 0, ((size_t)rows + 1) * sizeof(int)));
+    HIPCHK(w.order.upload(g_order.data(), g_order.size()));
+    HIPCHK(w.grow0.upload(grow0.data(), grow0.size()));
+    HIPCHK(w.chunk_iv.upload(chunk_iv.data(), chunk_iv.size()));
+    HIPCHK(w.chunk_t0.upload(chunk_t0.data(), chunk_t0.size()));
+    IntervalTab giv = iv;
+    giv.order = w.order.p;
+    giv.out0 = w.grow0.p;
+    const int n_iv = (int)g_order.size(), n_chunks = (int)chunk_iv.size();
+#define CALL(NT_) launch_estep<NT_>(m, giv, em, ratio, n_iv, n_chunks, w, b->ratios.p, b->sP)
+    TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(b->sP));
+    std::vector<double> lp((size_t)b->n);
+    std::vector<int> dead((size_t)b->n);
+    HIPCHK(hipMemcpy(lp.data(), w.fwd_lp.p, (size_t)b->n * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dead.data(), w.dead.p, (size_t)b->n * sizeof(int), hipMemcpyDeviceToHost));
+    for (int id : g_order) {
+      lp_total += lp[(size_t)id];
+      dead_any |= dead[(size_t)id];
+    }
+  }
+  std::vector<double> hC((size_t)NP * NP), hD(NP), hS(NP), hst((size_t)m->R * NP);
+  HIPCHK(hipMemcpy(hC.data(), w.C.p, hC.size() * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hD.data(), w.D.p, hD.size() * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hS.data(), w.start.p, hS.size() * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hst.data(), w.stat.p, hst.size() * sizeof(double), hipMemcpyDeviceToHost));
+  const double nan = std::nan("");
+  const double invN = 1.0 / (double)N;
+  for (int i = 0; i < N; ++i) {
+    start[i] += dead_any ? nan : hS[i];
+    for (int j = 0; j < N; ++j) {
+      double v = std::exp(m->h_lt[(size_t)i * N + j]) * hC[(size_t)i * NP + j];
+      if (i == j) v += hD[i];
+      trans[(size_t)i * N + j] += dead_any ? nan : v * invN;
+    }
+  }
+  for (int k = 0; k < K; ++k)
+    for (int s2 = 0; s2 < m->rowcnt[k]; ++s2)
+      for (int j = 0; j < N; ++j)
+        obsStats[((size_t)k * N + j) * S + s2] += dead_any ? nan : hst[(size_t)(m->rowbase[k] + s2) * NP + j];
+  *logprob_sum = dead_any ? nan : lp_total;
+  return TEHMM_OK;
 }
-
 
 // Diagnostic: cycle stamps of the last cooperative kernel (only in the -DTEHMM_STAMPS build).
 int tehmm_debug_read_stamps(unsigned long long *out, int n) {

@@ -270,8 +270,7 @@ class MultitrackHmm(BaseHMM):
     def _do_estep(self, obs, stats):
         """E-step over all sequences.  When every sequence is a uint8 table the fused device entry
         point (tehmm_estep_batch) does the whole loop of basehmm.py:507-522 in one call."""
-        from . import _lib
-        if self._can_fuse(obs) and _fused_estep_available():
+        if self._can_fuse(obs) and self.n_components < 64:
             return self._fused_estep(obs, stats)
         return BaseHMM._do_estep(self, obs, stats)
 
@@ -424,10 +423,6 @@ class MultitrackHmm(BaseHMM):
         d = dict(self.__dict__)
         d["_dev"] = None            # device handles are not picklable / copyable
         return d
-
-
-def _fused_estep_available():
-    return False
 
 
 def _merge_results(res_a, res_b, mask):

@@ -162,3 +162,31 @@ def test_fused_batch_ragged(hip, N, with_ratio):
     t = hb.timing()
     assert set(t) in ({"viterbi", "traceback", "forward", "backward_posterior"},
                       {"viterbi", "traceback", "forward_backward", "posterior_combine"})
+
+
+@pytest.mark.parametrize("N,with_ratio", [(35, 0), (35, 1), (6, 1), (20, 0)])
+def test_fused_estep_vs_oracle(hip, N, with_ratio):
+    """tehmm_estep_batch (basehmm.py:504-523 + hmm.py:545-574 fused on the device) against the
+    oracle's per-sequence E-step, ragged lengths including 1, 2 and chunk-boundary sizes."""
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    from oracle import oracle
+    model = synth.make_model(N, seed=3 + N, sparse=0.2)
+    lens = [1, 2, 700, 511, 512, 513, 1025, 64, 3]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = synth.sample_obs(model, int(offs[-1]), seed=6, missing=0.03)
+    ratios = synth.random_ratios(int(offs[-1]), seed=2) if with_ratio else None
+    K, _, S = model.log_probs.shape
+    start = np.zeros(N)
+    trans = np.zeros((N, N))
+    st = np.full((K, N, S), 0.5)
+    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, 1.0, model.symbols_per_track)
+    hb = HipBatch(obs, offs, ratios)
+    lp = hm.estep(hb, bool(with_ratio), start, trans, st)
+    seqs = [obs[offs[i]:offs[i + 1]] for i in range(len(lens))]
+    rl = [ratios[offs[i]:offs[i + 1]] for i in range(len(lens))] if with_ratio else None
+    ref = oracle.estep(seqs, model.log_probs, model.log_startprob, model.log_transmat, 1.0, rl)
+    assert_allclose(lp, ref["logprob"], rtol=RTOL)
+    assert_allclose(start, ref["start"], rtol=RTOL, atol=1e-13)
+    assert_allclose(trans, ref["trans"], rtol=RTOL, atol=1e-13)
+    assert_allclose(st, ref["obs"] + 0.5, rtol=RTOL, atol=1e-13)
