@@ -94,7 +94,17 @@ struct tehmm_model {
   std::vector<double> h_lt;   // [N][N] host copy (diag etc.)
 };
 
+// workspace of the fused E-step, kept with the batch so that EM iterations reuse it
+struct EstepWork {
+  DBuf<double> alpha, beta, wrows, fwd_lp, C, D, start, stat;
+  DBuf<int> escale, dead, order, chunk_iv;
+  DBuf<int64_t> grow0, chunk_t0;
+  int64_t rows_cap = 0;
+  int n_cap = 0, N = 0;
+};
+
 struct tehmm_batch {
+  EstepWork ew;
   int n = 0, K = 0, KP = 0;
   int64_t total = 0;       // user rows
   int64_t total_pad = 0;   // internal positions (64-aligned per interval)
@@ -784,12 +794,6 @@ int tehmm_viterbi(int64_t T, int N, const double *pi, const double *lt, const do
 namespace {
 constexpr int kEstepChunk = 512;
 
-struct EstepWork {
-  DBuf<double> alpha, beta, wrows, fwd_lp, C, D, start, stat;
-  DBuf<int> escale, dead, order, chunk_iv;
-  DBuf<int64_t> grow0, chunk_t0;
-};
-
 template <int NT>
 void launch_estep(const tehmm_model *m, const IntervalTab &iv, const EmisTab &em, bool ratio, int n_iv,
                   int n_chunks, EstepWork &w, const double *tratios, hipStream_t st) {
@@ -832,11 +836,16 @@ int tehmm_estep_batch(tehmm_model_t *m, tehmm_batch_t *b, int use_ratios, double
   // (3 x 8N + 4 bytes per position): the 3 Gb training sets of config 4 never materialise
   // whole-genome lattices.
   const int64_t budget_rows = std::max<int64_t>((int64_t)(12ll << 30) / (24 * N + 4), 1);
-  EstepWork w;
-  HIPCHK(w.C.alloc((size_t)NP * NP));
-  HIPCHK(w.D.alloc((size_t)NP));
-  HIPCHK(w.start.alloc((size_t)NP));
-  HIPCHK(w.stat.alloc((size_t)m->R * NP));
+  EstepWork &w = b->ew;
+  if (w.N != N || !w.C.p) {
+    HIPCHK(w.C.alloc((size_t)NP * NP));
+    HIPCHK(w.D.alloc((size_t)NP));
+    HIPCHK(w.start.alloc((size_t)NP));
+    HIPCHK(w.stat.alloc((size_t)m->R * NP));
+    w.alpha.release();
+    w.rows_cap = 0;
+    w.N = N;
+  }
   HIPCHK(hipMemset(w.C.p, 0, (size_t)NP * NP * sizeof(double)));
   HIPCHK(hipMemset(w.D.p, 0, (size_t)NP * sizeof(double)));
   HIPCHK(hipMemset(w.start.p, 0, (size_t)NP * sizeof(double)));
@@ -868,12 +877,18 @@ int tehmm_estep_batch(tehmm_model_t *m, tehmm_batch_t *b, int use_ratios, double
       ++pos_in_order;
     }
     if (rows == 0) continue;
-    HIPCHK(w.alpha.alloc((size_t)rows * N + 1));
-    HIPCHK(w.beta.alloc((size_t)rows * N + 1));
-    HIPCHK(w.wrows.alloc((size_t)rows * N + 1));
-    HIPCHK(w.escale.alloc((size_t)rows + 1));
-    HIPCHK(w.fwd_lp.alloc((size_t)b->n + 1));
-    HIPCHK(w.dead.alloc((size_t)b->n + 1));
+    if (rows > w.rows_cap) {
+      HIPCHK(w.alpha.alloc((size_t)rows * N + 1));
+      HIPCHK(w.beta.alloc((size_t)rows * N + 1));
+      HIPCHK(w.wrows.alloc((size_t)rows * N + 1));
+      HIPCHK(w.escale.alloc((size_t)rows + 1));
+      w.rows_cap = rows;
+    }
+    if (b->n > w.n_cap) {
+      HIPCHK(w.fwd_lp.alloc((size_t)b->n + 1));
+      HIPCHK(w.dead.alloc((size_t)b->n + 1));
+      w.n_cap = b->n;
+    }
     HIPCHK(hipMemset(w.dead.p, 0, (size_t)(b->n + 1) * sizeof(int)));
     HIPCHK(hipMemset(w.escale.p, 0, ((size_t)rows + 1) * sizeof(int)));
     HIPCHK(w.order.upload(g_order.data(), g_order.size()));
