@@ -493,6 +493,16 @@ static void fill_tabs(const tehmm_model *m, const tehmm_batch *b, IntervalTab &i
   em.ltab_src = m->ltab.p;
 }
 
+// With more intervals than CUs the forward/backward kernel is throughput-bound: dropping the LDS
+// copy of the small-track tables (they then come from L2) brings its LDS below 80 KB so that two
+// workgroups share a CU.
+static EmisTab without_lds_tables(const EmisTab &em) {
+  EmisTab e = em;
+  e.lds_rows = 0;
+  for (int k = 0; k < TEHMM_MAX_TRACKS; ++k) e.ldsbase[k] = -1;
+  return e;
+}
+
 static int ensure_workspace(tehmm_batch *b, const tehmm_model *m, int flags) {
   if (b->N != m->N) {
     b->paths.release();
@@ -573,9 +583,10 @@ static void launch_vit_coop(tehmm_batch *b, const tehmm_model *m, const Interval
 
 template <int NT>
 static void launch_fb_coop(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv,
-                           const EmisTab &em, hipStream_t st) {
+                           const EmisTab &em_in, hipStream_t st) {
   constexpr int CPB = NT <= 44 ? 64 : 32;
-  size_t lds = ((size_t)4 * CPB * (NT + 1) + 4 * CPB + 5 * NT + (size_t)m->lds_rows * NT) * sizeof(double);
+  const EmisTab em = b->n > 256 ? without_lds_tables(em_in) : em_in;
+  size_t lds = ((size_t)4 * CPB * (NT + 1) + 4 * CPB + 5 * NT + (size_t)em.lds_rows * NT) * sizeof(double);
   allow_lds(k_fb_coop<NT, CPB, false>, lds);
   hipLaunchKernelGGL((k_fb_coop<NT, CPB, false>), dim3(b->n), dim3(256), lds, st, iv, em, m->N, m->A.p,
                      m->lt.p, m->pi.p, (const double *)nullptr, b->post.p, b->beta.p, b->fwd_lp.p,
@@ -798,11 +809,12 @@ template <int NT>
 void launch_estep(const tehmm_model *m, const IntervalTab &iv, const EmisTab &em, bool ratio, int n_iv,
                   int n_chunks, EstepWork &w, const double *tratios, hipStream_t st) {
   constexpr int CPB = NT <= 44 ? 64 : 32;
-  size_t lds = ((size_t)4 * CPB * (NT + 1) + 4 * CPB + 5 * NT + (size_t)m->lds_rows * NT) * sizeof(double);
+  const EmisTab emf = n_iv > 256 ? without_lds_tables(em) : em;
+  size_t lds = ((size_t)4 * CPB * (NT + 1) + 4 * CPB + 5 * NT + (size_t)emf.lds_rows * NT) * sizeof(double);
   size_t lds2 = (size_t)std::max(1, m->lds_rows) * NT * sizeof(double);
   if (ratio) {
     allow_lds(k_fb_coop<NT, CPB, true>, lds);
-    hipLaunchKernelGGL((k_fb_coop<NT, CPB, true>), dim3(n_iv), dim3(256), lds, st, iv, em, m->N, m->A.p,
+    hipLaunchKernelGGL((k_fb_coop<NT, CPB, true>), dim3(n_iv), dim3(256), lds, st, iv, emf, m->N, m->A.p,
                        m->lt.p, m->pi.p, tratios, w.alpha.p, w.beta.p, w.fwd_lp.p, w.dead.p, w.wrows.p,
                        w.escale.p);
     allow_lds(k_estep_accum<NT, true>, lds2);
@@ -811,7 +823,7 @@ void launch_estep(const tehmm_model *m, const IntervalTab &iv, const EmisTab &em
                        w.wrows.p, w.escale.p, w.C.p, w.D.p, w.start.p, w.stat.p);
   } else {
     allow_lds(k_fb_coop<NT, CPB, false>, lds);
-    hipLaunchKernelGGL((k_fb_coop<NT, CPB, false>), dim3(n_iv), dim3(256), lds, st, iv, em, m->N, m->A.p,
+    hipLaunchKernelGGL((k_fb_coop<NT, CPB, false>), dim3(n_iv), dim3(256), lds, st, iv, emf, m->N, m->A.p,
                        m->lt.p, m->pi.p, (const double *)nullptr, w.alpha.p, w.beta.p, w.fwd_lp.p,
                        w.dead.p, w.wrows.p, w.escale.p);
     allow_lds(k_estep_accum<NT, false>, lds2);
@@ -833,9 +845,13 @@ int tehmm_estep_batch(tehmm_model_t *m, tehmm_batch_t *b, int use_ratios, double
   const bool ratio = use_ratios && b->has_ratios;
   const int N = m->N, NP = m->NP, K = m->K, S = m->S;
   // Intervals are processed in groups whose alpha / beta / w rows fit a fixed workspace
-  // (3 x 8N + 4 bytes per position): the 3 Gb training sets of config 4 never materialise
-  // whole-genome lattices.
-  const int64_t budget_rows = std::max<int64_t>((int64_t)(12ll << 30) / (24 * N + 4), 1);
+  // (3 x 8N + 4 bytes per position, 40 % of the free HBM): the 3 Gb training sets of config 4
+  // never materialise whole-genome lattices.
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  int64_t budget_bytes = (int64_t)((double)(free_b + (size_t)b->ew.rows_cap * (24 * N + 4)) * 0.4);
+  if (budget_bytes < (4ll << 30)) budget_bytes = 4ll << 30;
+  const int64_t budget_rows = std::max<int64_t>(budget_bytes / (24 * N + 4), 1);
   EstepWork &w = b->ew;
   if (w.N != N || !w.C.p) {
     HIPCHK(w.C.alloc((size_t)NP * NP));
