@@ -739,15 +739,16 @@ __global__ __launch_bounds__(256) void k_estep_accum(IntervalTab iv, EmisTab em,
 // reference's lattices are NaN from there on; make the outputs say so.
 __global__ void k_poison_dead(IntervalTab iv, const int *dead_flag, int N, double *post,
                               double *fwd_logprob) {
-  const int id = blockIdx.y;
-  if (id >= iv.n || !dead_flag[id]) return;
-  const int64_t T = iv.len[id];
-  double *o = post + iv.out0[id] * N;
   const double nan = __longlong_as_double(0x7ff8000000000000LL);
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < T * N;
-       i += (int64_t)gridDim.x * blockDim.x)
-    o[i] = nan;
-  if (blockIdx.x == 0 && threadIdx.x == 0) fwd_logprob[id] = nan;
+  for (int id = blockIdx.y; id < iv.n; id += gridDim.y) {
+    if (!dead_flag[id]) continue;
+    const int64_t T = iv.len[id];
+    double *o = post + iv.out0[id] * N;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < T * N;
+         i += (int64_t)gridDim.x * blockDim.x)
+      o[i] = nan;
+    if (blockIdx.x == 0 && threadIdx.x == 0) fwd_logprob[id] = nan;
+  }
 }
 
 }  // namespace tehmm

@@ -436,14 +436,13 @@ int tehmm_batch_create(int n, const int64_t *offsets, int K, const uint8_t *obs,
   }
   if (e == hipSuccess && n > 0 && b->total > 0) {
     int64_t maxT = b->h_len[b->h_order[0]];
-    dim3 grid(grid_for(maxT * b->KP, 256, 1024), n);
-    // gridDim.y is limited to 65535
-    if (n > 65535) {
-      delete b;
-      return fail(TEHMM_ERR_UNSUPPORTED, "tehmm_batch_create: more than 65535 intervals per batch");
+    // gridDim.y is limited to 65535: repack in slices of intervals
+    for (int i0 = 0; i0 < n; i0 += 32768) {
+      const int cnt = std::min(32768, n - i0);
+      dim3 grid(grid_for(maxT * b->KP, 256, cnt > 1024 ? 16 : 1024), cnt);
+      hipLaunchKernelGGL(k_repack_obs, grid, dim3(256), 0, 0, cnt, b->d_out0.p + i0, b->d_pos0.p + i0,
+                         b->d_len.p + i0, K, b->KP, src, b->obs.p, rsrc, b->ratios.p);
     }
-    hipLaunchKernelGGL(k_repack_obs, grid, dim3(256), 0, 0, n, b->d_out0.p, b->d_pos0.p, b->d_len.p, K,
-                       b->KP, src, b->obs.p, rsrc, b->ratios.p);
     up(hipGetLastError());
     up(hipDeviceSynchronize());
   }
@@ -659,7 +658,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       (void)hipEventRecord(b->ev[evi + 1], st);
       hipLaunchKernelGGL((k_combine<true>), dim3(grid_for(b->total * 16, 256, 256 * 16)), dim3(256), 0, st,
                          b->total, m->N, b->post.p, b->beta.p);
-      hipLaunchKernelGGL(k_poison_dead, dim3(64, b->n), dim3(256), 0, st, iv, b->dead.p, m->N, b->post.p,
+      hipLaunchKernelGGL(k_poison_dead, dim3(64, std::min(b->n, 1024)), dim3(256), 0, st, iv, b->dead.p, m->N, b->post.p,
                          b->fwd_lp.p);
     } else if (SPL == 1) launch_posterior<1>(b, m, iv, em, st, b->ev[evi + 1]);
     else launch_posterior<2>(b, m, iv, em, st, b->ev[evi + 1]);
