@@ -103,7 +103,8 @@ def main():
     torch.cuda.set_device(local_rank)
     _lib.check(_lib.load().tehmm_set_device(local_rank), "tehmm_set_device")
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ      # torchrun (even with one rank) -> RCCL path
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
 
@@ -121,7 +122,7 @@ def main():
     torch.cuda.empty_cache()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -136,7 +137,7 @@ def main():
             kt.setdefault(name, []).append(ms)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -153,6 +154,12 @@ def main():
         alg = {"viterbi": K + 8, "backward_posterior": K + 8 * N, "forward": K, "traceback": 8,
                "forward_backward": K, "posterior_combine": 8 * N}
         achieved = alg[dom] * float(total) / (kavg[dom] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):     # HBM bytes per position measured with rocprofv3 --pmc (see file)
+            per_pos = json.load(open(tpath)).get("hbm_bytes_per_position", {}).get(dom)
+            if per_pos is not None:
+                traffic = per_pos * float(total)
         out = {
             "metric": "genome positions/sec (Viterbi+posterior), 35 states x 10 tracks",
             "value": value, "unit": "positions/s", "n_gpus": world, "steps": args.steps,
@@ -166,7 +173,7 @@ def main():
                        "positions_per_gpu": total, "intervals_per_gpu": int(len(lens)),
                        "parallelism": "intervals sharded over %d GPU(s), no collective" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "alg_bytes_per_position": alg[dom],
                          "whole_path_GBps": (K + 8 + 8 * N) * value / world / 1e9},
             "kernel_ms": kavg,
@@ -175,7 +182,7 @@ def main():
             nthr = max(1, min(16, os.cpu_count() or 1))
             out["cpu_baseline"] = cpu_baseline(model, nthr, args.cpu_sample_kb * 1000)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

