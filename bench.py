@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--min-kb", type=int, default=200, help="shortest interval (kb)")
     ap.add_argument("--max-kb", type=int, default=2000, help="longest interval (kb)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the untimed extra measurement (BASELINE configs[1]: one 10 Mb interval)")
     ap.add_argument("--cpu-sample-kb", type=int, default=250,
                     help="positions per CPU-baseline interval (kb); 4 intervals per thread")
     args = ap.parse_args()
@@ -178,6 +180,24 @@ def main():
                          "whole_path_GBps": (K + 8 + 8 * N) * value / world / 1e9},
             "kernel_ms": kavg,
         }
+        if world == 1 and not args.no_extra:
+            # BASELINE.json configs[1] for orientation (NOT the headline): the same model on ONE
+            # 10 Mb interval -- a single dependent chain, i.e. pure per-step latency.
+            hb.close()
+            one = np.asarray([10_000_000], dtype=np.int64)
+            obs1 = gen_obs_torch(model, one, seed=99, device=device)
+            hb1 = HipBatch(obs1.data_ptr(), np.asarray([0, one[0]], dtype=np.int64), device_ptrs=True,
+                           K=model.n_tracks)
+            hm.eval(hb1, viterbi=True, posterior=True)      # warm-up (allocates the result buffers)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            hm.eval(hb1, viterbi=True, posterior=True)
+            d1 = time.perf_counter() - t1
+            out["extra"] = {"config2_single_10Mb_interval": {
+                "value": float(one[0]) / d1, "unit": "positions/s", "ms": d1 * 1e3,
+                "kernel_ms": hb1.timing()}}
+            hb1.close()
+            del obs1
         if world == 1 and not args.no_cpu_baseline:
             nthr = max(1, min(16, os.cpu_count() or 1))
             out["cpu_baseline"] = cpu_baseline(model, nthr, args.cpu_sample_kb * 1000)

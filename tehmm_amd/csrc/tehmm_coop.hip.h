@@ -6,9 +6,9 @@
 // give every interval a whole workgroup of 4 wavefronts (one per SIMD of a CU) and strip the chain
 // wave down to the bare recurrence:
 //   * the chain wave runs only the value recurrence: lane = destination state, its column of the
-//     transition table in registers; the previous state vector reaches every lane partly by
-//     v_readlane (straight from the register, which covers the LDS write->read latency) and
-//     partly by LDS broadcast reads (ds_read_b128, two states per instruction);
+//     transition table in registers; the previous state vector reaches every lane by DPP row
+//     broadcasts out of registers (no LDS, no readlane on the recurrence: measured 16 cycles per
+//     ds_read_b128 and 7 per v_readlane for a lone wave, against 4.7 for a DPP move);
 //   * helper waves compute, one 64-position block ahead, the emission rows (lane = position, so
 //     the table gathers of 64 positions are all in flight together; small tracks' tables are
 //     staged in LDS) and, one block behind, whatever is parallel over positions: the Viterbi
@@ -22,21 +22,15 @@
 
 namespace tehmm {
 
-// LDS broadcast reads of a whole state vector: the row address is laundered through an opaque
-// v_mov so that it stays in ONE VGPR and the unrolled reads become
-// `ds_read_b128 v, vbase offset:imm` (one instruction each).
+// Reading a whole LDS row with unrolled ds_read_b128: the row address is laundered through an
+// opaque v_mov so that it stays in ONE VGPR and the reads become `ds_read_b128 v, vbase offset:imm`
+// (one instruction each).
 typedef double d2v __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const d2v lds_cd2;
 __device__ __forceinline__ lds_cd2 *lds_row(const double *row) {
   unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) const double *)row;
   asm volatile("v_mov_b32 %0, %1" : "=v"(a) : "v"(a));
   return (lds_cd2 *)(size_t)a;
-}
-
-__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-  return __hiloint2double(hi, lo);
 }
 
 // ---- state-vector broadcast without LDS -------------------------------------------------------
@@ -97,17 +91,6 @@ struct BcastFma<NT, NT> {
                                              double (&)[4]) {}
 };
 
-__device__ __forceinline__ int wave_max_i32_dpp(int v) {
-  const int ident = (int)0x80000000;
-  v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x111, 0xf, 0xf, false));   // row_shr:1
-  v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x112, 0xf, 0xf, false));   // row_shr:2
-  v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x114, 0xf, 0xf, false));   // row_shr:4
-  v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x118, 0xf, 0xf, false));   // row_shr:8
-  v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x142, 0xa, 0xf, false));   // row_bcast:15
-  v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x143, 0xc, 0xf, false));   // row_bcast:31
-  return __builtin_amdgcn_readlane(v, 63);
-}
-
 // exp(y) for y <= 0 (the only range the scaled emission needs): k = rint(y/ln2),
 // r = y - k*ln2 (two-piece ln2), degree-13 Taylor polynomial (|r| <= 0.347: truncation 4e-18),
 // ldexp.  About 1 ulp; ~22 VALU instructions instead of the generic libm path.
@@ -132,12 +115,6 @@ __device__ __forceinline__ double exp_nonpos(double y) {
   const double res = ldexp(p, (int)k);
   return y < -1100.0 ? 0.0 : res;               // also maps -inf to 0; NaN stays NaN
 }
-
-// Emission tables for the cooperative kernels: rows of tracks flagged in_lds are served from the
-// LDS copy `ltab` (row index lds_base[k] + symbol), the others from global memory.
-struct EmisLds {
-  const double *ltab;     // LDS [lds_rows][NT]
-};
 
 // Emission log-likelihood of ONE position per lane, all NT (padded) states in registers.
 // Operation order per state as in _emission.pyx:65-72.  Table rows are [NT] doubles (pads 0).

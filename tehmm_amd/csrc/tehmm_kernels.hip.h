@@ -1,8 +1,11 @@
-// tehmm_kernels.hip.h -- device code of libtehmm_hip.so (gfx950 / CDNA4, wave64).
+// tehmm_kernels.hip.h -- device code of libtehmm_hip.so (gfx950 / CDNA4, wave64): shared types,
+// the array-level kernels (1:1 with the reference's Cython functions), the traceback kernels and
+// the generic one-wave-per-interval fused kernels used for 64 <= N <= 128.  The cooperative
+// kernels of the main path (N < 64) are in tehmm_coop.hip.h.
 //
 // Layout conventions (device side)
-//   * one wavefront owns one interval (TrackTable); lane j (and j+64 when SPL==2) owns state j;
-//   * the N x N transition table lives in LDS as [from][NP] rows so that "lane = to" reads are
+//   * generic kernels: one wavefront owns one interval; lane j (and j+64 when SPL==2) owns state
+//     j; the N x N transition table lives in LDS as [from][NP] rows so that "lane = to" reads are
 //     conflict-free ds_read_b64 and the previous state vector is an LDS broadcast read;
 //   * observations are repacked to [position][KP] bytes (KP = K rounded up to 4) so that one row
 //     is a wave-uniform (scalar) load; emission tables are packed [row][NP] with one row per
@@ -86,9 +89,6 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
   return v;
-}
-__device__ __forceinline__ double pij_safe(const double *pi, int j, int N) {
-  return j < N ? pi[j] : -INFINITY;
 }
 // frexp-style exponent of a non-negative double (0 -> -1022)
 __device__ __forceinline__ int exp_of(double a) {
