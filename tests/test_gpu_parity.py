@@ -229,3 +229,47 @@ def test_config2_single_long_interval(hip):
     assert_allclose(post_p, post_o, rtol=RTOL, atol=1e-15)
     # far from the prefix end the posteriors of the long run equal those of the prefix run
     assert_allclose(post[:Tp - 2000], post_p[:Tp - 2000], rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fused_random_shapes(hip, seed):
+    """Randomised shapes through the fused path: N from 1 to 63 (every padded tile size), 1-20
+    tracks incl. 255-symbol tracks, emFac normalisation, sparse transitions (-1e100), missing data,
+    ragged interval lengths, with and without segment ratios -- against the oracle drivers."""
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    from oracle import oracle
+    rs = np.random.RandomState(1000 + seed)
+    N = int(rs.choice([1, 2, 3, 4, 7, 8, 11, 15, 16, 17, 23, 31, 32, 33, 39, 40, 47, 55, 56, 63]))
+    K = int(rs.randint(1, 21))
+    syms = [int(rs.choice([1, 2, 3, 5, 17, 100, 255])) for _ in range(K)]
+    gauss = [k for k in range(K) if syms[k] >= 100 and rs.rand() < 0.5]
+    model = synth.make_model(N, syms, gauss, seed=seed, sparse=float(rs.choice([0.0, 0.3, 0.7])))
+    normalize = float(rs.choice([1.0, 1.0, 3.0 / K]))
+    n_iv = int(rs.randint(1, 9))
+    lens = [int(x) for x in rs.choice([1, 2, 5, 63, 64, 65, 129, 300, 1000], size=n_iv)]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = synth.sample_obs(model, int(offs[-1]), seed=seed, missing=0.05)
+    with_ratio = bool(rs.rand() < 0.5)
+    ratios = synth.random_ratios(int(offs[-1]), seed=seed) if with_ratio else None
+    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, normalize,
+                  model.symbols_per_track if rs.rand() < 0.7 else None)
+    hb = HipBatch(obs, offs, ratios)
+    res = hm.eval(hb, viterbi=True, posterior=True)
+    p_o, vlp_o, flp_o, post_o = oracle.eval_batch(obs, offs, model.log_probs, model.log_startprob,
+                                                  model.log_transmat, normalize, ratios, n_threads=4)
+    assert_array_equal(hb.paths(), p_o)
+    assert_array_equal(res["viterbi_logprob"], vlp_o)
+    assert_allclose(res["forward_logprob"], flp_o, rtol=RTOL)
+    assert_allclose(hb.posteriors(), post_o, rtol=RTOL, atol=1e-15)
+    # and the fused E-step on the same batch
+    Kk, _, S = model.log_probs.shape
+    start, trans, st = np.zeros(N), np.zeros((N, N)), np.zeros((Kk, N, S))
+    lp = hm.estep(hb, with_ratio, start, trans, st)
+    seqs = [obs[offs[i]:offs[i + 1]] for i in range(n_iv)]
+    rl = [ratios[offs[i]:offs[i + 1]] for i in range(n_iv)] if with_ratio else None
+    ref = oracle.estep(seqs, model.log_probs, model.log_startprob, model.log_transmat, normalize, rl)
+    assert_allclose(lp, ref["logprob"], rtol=RTOL)
+    assert_allclose(start, ref["start"], rtol=RTOL, atol=1e-12)
+    assert_allclose(trans, ref["trans"], rtol=RTOL, atol=1e-12)
+    assert_allclose(st, ref["obs"], rtol=RTOL, atol=1e-12)
