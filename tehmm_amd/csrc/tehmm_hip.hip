@@ -2,10 +2,12 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see tehmm_amd/build.py).
 #include "tehmm_kernels.hip.h"
 #include "tehmm_coop.hip.h"
+#include "tehmm_spec.hip.h"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -103,8 +105,19 @@ struct EstepWork {
   int n_cap = 0, N = 0;
 };
 
+// chunk bookkeeping of the speculative (chunk-parallel, exact) Viterbi
+struct SpecWork {
+  int CS = 0, n_chunks = 0, N = 0;
+  std::vector<int> h_iv;
+  std::vector<int64_t> h_t0, h_first;
+  DBuf<int> iv, e, ok, stats, ntie, ties;
+  DBuf<int64_t> t0, first;
+  DBuf<double> gain, wmin, rows, tierows;
+};
+
 struct tehmm_batch {
   EstepWork ew;
+  SpecWork sw;
   int n = 0, K = 0, KP = 0;
   int64_t total = 0;       // user rows
   int64_t total_pad = 0;   // internal positions (64-aligned per interval)
@@ -592,6 +605,97 @@ static void launch_fb_coop(tehmm_batch *b, const tehmm_model *m, const IntervalT
                      b->dead.p, (double *)nullptr, (int *)nullptr);
 }
 
+// ---- speculative chunk-parallel exact Viterbi (no segment ratios) ----------------------------
+static int spec_chunk_size() {
+  const char *s = std::getenv("TEHMM_SPEC_CHUNK");     // 0 disables; tests use small chunks
+  int cs = s ? std::atoi(s) : 4096;
+  if (cs <= 0) return 0;
+  return std::max(64, (cs + 63) & ~63);
+}
+
+static int spec_prepare(tehmm_batch *b, const tehmm_model *m, int CS) {
+  SpecWork &sw = b->sw;
+  if (sw.CS == CS && sw.N == m->N && sw.rows.p) return TEHMM_OK;
+  sw.CS = CS;
+  sw.N = m->N;
+  sw.h_iv.clear();
+  sw.h_t0.clear();
+  sw.h_first.assign((size_t)b->n + 1, 0);
+  for (int i = 0; i < b->n; ++i) {
+    sw.h_first[i] = (int64_t)sw.h_iv.size();
+    for (int64_t t0 = 0; t0 < b->h_len[i]; t0 += CS) {
+      sw.h_iv.push_back(i);
+      sw.h_t0.push_back(t0);
+    }
+  }
+  sw.h_first[b->n] = (int64_t)sw.h_iv.size();
+  sw.n_chunks = (int)sw.h_iv.size();
+  const size_t nc = (size_t)std::max(1, sw.n_chunks);
+  HIPCHK(sw.iv.upload(sw.h_iv.data(), sw.h_iv.size()));
+  HIPCHK(sw.t0.upload(sw.h_t0.data(), sw.h_t0.size()));
+  HIPCHK(sw.first.upload(sw.h_first.data(), sw.h_first.size()));
+  HIPCHK(sw.e.alloc(nc));
+  HIPCHK(sw.ok.alloc(nc));
+  HIPCHK(sw.stats.alloc(4));
+  HIPCHK(sw.gain.alloc(nc));
+  HIPCHK(sw.wmin.alloc(nc));
+  HIPCHK(sw.rows.alloc(nc * (size_t)(CS / 32) * m->NP));
+  HIPCHK(sw.ntie.alloc(nc));
+  HIPCHK(sw.ties.alloc(nc * TEHMM_SPEC_MAXT));
+  HIPCHK(sw.tierows.alloc(nc * TEHMM_SPEC_MAXT * (size_t)m->NP));
+  return TEHMM_OK;
+}
+
+// Which binade each chunk lives in, from the plain-fp chunk gains of pass P0 (approximate prefix
+// sums are enough: a wrong or risky guess only sends that chunk to the sequential chain).
+static void spec_assign_binades(const tehmm_batch *b, const std::vector<double> &gain, std::vector<int> &e) {
+  const SpecWork &sw = b->sw;
+  e.assign((size_t)std::max(1, sw.n_chunks), TEHMM_SPEC_NONE);
+  for (int i = 0; i < b->n; ++i) {
+    double v = 0.0;
+    for (int64_t c = sw.h_first[i]; c < sw.h_first[i + 1]; ++c) {
+      const double g = gain[(size_t)c];
+      const double vs = v, ve = v + g;
+      v = ve;
+      const bool full = sw.h_t0[(size_t)c] + sw.CS <= b->h_len[i];
+      if (c == sw.h_first[i] || !full || !(g == g) || !(g < 0.0)) continue;
+      const double margin = 512.0 + 2e-3 * std::fabs(ve);
+      const double lo = std::fabs(vs) - margin, hi = std::fabs(ve) + margin;
+      if (!(lo > 0.0)) continue;
+      int ex = 0;
+      (void)std::frexp(lo, &ex);          // lo = f * 2^ex, f in [0.5, 1)  ->  binade exponent ex - 1
+      const int be = ex - 1;
+      if (be < TEHMM_SPEC_MIN_E || !(hi < std::ldexp(1.0, be + 1))) continue;
+      e[(size_t)c] = be;
+    }
+  }
+}
+
+template <int NT>
+static void launch_vit_spec(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em,
+                            const VitChunks &vc, bool quant, hipStream_t st) {
+  size_t lds = (size_t)4 * 64 * (NT + 1) * sizeof(double) + 4 * 64 * sizeof(int);
+  const int grid = std::min((vc.n + 3) / 4, 4096);
+  if (quant) {
+    allow_lds(k_vit_spec<NT, true>, lds);
+    hipLaunchKernelGGL((k_vit_spec<NT, true>), dim3(grid), dim3(256), lds, st, iv, em, vc, m->N, m->lt.p,
+                       b->tb.p);
+  } else {
+    allow_lds(k_vit_spec<NT, false>, lds);
+    hipLaunchKernelGGL((k_vit_spec<NT, false>), dim3(grid), dim3(256), lds, st, iv, em, vc, m->N, m->lt.p,
+                       b->tb.p);
+  }
+}
+
+template <int NT>
+static void launch_vit_fix(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em,
+                           const VitChunks &vc, hipStream_t st) {
+  size_t lds = ((size_t)3 * 64 * (NT + 1) + 2 * 65 * (NT + 2) + (size_t)m->lds_rows * NT + 8) * sizeof(double);
+  allow_lds(k_vit_fix<NT>, lds);
+  hipLaunchKernelGGL((k_vit_fix<NT>), dim3(b->n), dim3(256), lds, st, iv, em, vc, m->N, m->lt.p, m->ltT.p,
+                     m->pi.p, b->tb.p, b->last_state.p, b->vit_lp.p, b->sw.stats.p);
+}
+
 #define TEHMM_NT_DISPATCH(NP_, CALL)                                                                \
   switch (NP_) {                                                                                    \
     case 4: CALL(4); break;   case 8: CALL(8); break;   case 12: CALL(12); break;                   \
@@ -624,7 +728,38 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   if (flags & TEHMM_EVAL_VITERBI) {
     hipStream_t st = b->sV;
     (void)hipEventRecord(b->ev[evi], st);
-    if (coop) {
+    const int CS = spec_chunk_size();
+    bool spec_done = false;
+    if (coop && !ratio && CS > 0 && m->NP <= 44 && b->total >= 2 * (int64_t)CS) {
+      // chunk-parallel exact Viterbi: P0 (plain gains) -> binades -> P2 (quantised) -> fix-up chain
+      rc = spec_prepare(b, m, CS);
+      if (rc) return rc;
+      SpecWork &sw = b->sw;
+      VitChunks vc;
+      vc.iv = sw.iv.p; vc.t0 = sw.t0.p; vc.first = sw.first.p; vc.n = sw.n_chunks; vc.CS = CS;
+      vc.e = sw.e.p; vc.gain = sw.gain.p; vc.ok = sw.ok.p; vc.wmin = sw.wmin.p; vc.rows = sw.rows.p;
+      vc.ntie = sw.ntie.p; vc.ties = sw.ties.p; vc.tierows = sw.tierows.p;
+      const EmisTab emg = without_lds_tables(em);
+#define CALL(NT_) launch_vit_spec<NT_>(b, m, iv, emg, vc, false, st)
+      TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+      std::vector<double> gain((size_t)std::max(1, sw.n_chunks));
+      HIPCHK(hipMemcpyAsync(gain.data(), sw.gain.p, gain.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      std::vector<int> he;
+      spec_assign_binades(b, gain, he);
+      HIPCHK(hipMemcpyAsync(sw.e.p, he.data(), he.size() * sizeof(int), hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemsetAsync(sw.ok.p, 0, he.size() * sizeof(int), st));
+      HIPCHK(hipMemsetAsync(sw.stats.p, 0, 4 * sizeof(int), st));
+#define CALL(NT_) launch_vit_spec<NT_>(b, m, iv, emg, vc, true, st)
+      TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+      (void)hipEventRecord(b->ev[evi + 3], st);
+#define CALL(NT_) launch_vit_fix<NT_>(b, m, iv, em, vc, st)
+      TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+      spec_done = true;
+    } else if (coop) {
 #define CALL(NT_) launch_vit_coop<NT_>(b, m, iv, em, ratio, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
@@ -641,11 +776,18 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
                          b->n_chunks, b->d_chunk_iv.p, b->d_chunk0.p, b->TBW, b->tb.p, b->bstate.p,
                          b->paths.p);
     (void)hipEventRecord(b->ev[evi + 2], st);
-    b->tnames.push_back("viterbi");
-    b->tpairs.push_back({evi, evi + 1});
+    if (spec_done) {
+      b->tnames.push_back("viterbi_speculate");
+      b->tpairs.push_back({evi, evi + 3});
+      b->tnames.push_back("viterbi");
+      b->tpairs.push_back({evi + 3, evi + 1});
+    } else {
+      b->tnames.push_back("viterbi");
+      b->tpairs.push_back({evi, evi + 1});
+    }
     b->tnames.push_back("traceback");
     b->tpairs.push_back({evi + 1, evi + 2});
-    evi += 3;
+    evi += 4;
   }
   if (flags & TEHMM_EVAL_POSTERIOR) {
     hipStream_t st = b->sP;
@@ -676,6 +818,28 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, b->ev[pr.first], b->ev[pr.second]);
     b->tms.push_back((double)ms);
+  }
+  if ((flags & TEHMM_EVAL_VITERBI) && b->sw.stats.p && !b->tnames.empty() &&
+      b->tnames[0] == "viterbi_speculate") {
+    // counters (not times): 64-position blocks the exact chain ran / chunks it could jump over
+    int st[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(st, b->sw.stats.p, sizeof(st), hipMemcpyDeviceToHost));
+    if (std::getenv("TEHMM_SPEC_DEBUG")) {
+      std::vector<int> he((size_t)b->sw.n_chunks), hok((size_t)b->sw.n_chunks);
+      HIPCHK(hipMemcpy(he.data(), b->sw.e.p, he.size() * sizeof(int), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(hok.data(), b->sw.ok.p, hok.size() * sizeof(int), hipMemcpyDeviceToHost));
+      int na = 0, nok = 0;
+      for (size_t i = 0; i < he.size(); ++i) {
+        na += he[i] != TEHMM_SPEC_NONE;
+        nok += he[i] != TEHMM_SPEC_NONE && hok[i];
+      }
+      std::fprintf(stderr, "[tehmm spec] chunks %d, speculated %d, usable %d, jumped %d, exact blocks %d\n",
+                   b->sw.n_chunks, na, nok, st[1], st[0]);
+    }
+    b->tnames.push_back("count:viterbi_exact_blocks");
+    b->tms.push_back((double)st[0]);
+    b->tnames.push_back("count:viterbi_chunk_jumps");
+    b->tms.push_back((double)st[1]);
   }
   if ((flags & TEHMM_EVAL_VITERBI) && viterbi_logprob)
     HIPCHK(hipMemcpy(viterbi_logprob, b->vit_lp.p, (size_t)b->n * sizeof(double), hipMemcpyDeviceToHost));

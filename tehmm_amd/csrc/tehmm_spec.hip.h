@@ -1,0 +1,425 @@
+// tehmm_spec.hip.h -- chunk-parallel EXACT Viterbi: speculative chunk pass + sequential fix-up.
+//
+// Why this is exact.  The reference computes V_t[j] = fl( max_i fl(V_{t-1}[i] + lt[i][j]) + b_t[j] )
+// in fp64 (_hmm.pyx:229-247).  While every finite V value sits in one binade [2^e, 2^(e+1)) they
+// are all multiples of u = 2^(e-52), and adding an arbitrary double z to such a value rounds z to the
+// grid:  fl(v + z) = v + R_u(z)  (R_u = nearest multiple of u; exact ties are detected and excluded,
+// magnitudes only grow because every term is <= 0).  Inside a binade the recurrence is therefore an
+// EXACT integer max-plus recurrence with the quantised tables ltq = R_u(lt), bq_t = R_u(b_t): it is
+// translation invariant (V -> V + c gives the same arg-max decisions) and tropical matrix products
+// converge to rank one, so a chunk started from an ARBITRARY vector W makes, after a few steps, the
+// same decisions as the true chain and V_t - W_t becomes one constant delta (Maleki et al., "Parallelizing
+// dynamic programming through rank convergence", PPoPP 2014 -- here applied binade by binade so that
+// the fp64 rounding of the reference is reproduced bit for bit).
+//
+//   P0  k_vit_spec<QUANT=false>  every chunk from a zero vector in plain fp64: chunk score gains ->
+//       host prefix sum -> which binade each chunk lives in (chunks near a binade boundary, the first
+//       chunk of an interval and ragged tails are simply left to the sequential chain);
+//   P2  k_vit_spec<QUANT=true>   every speculated chunk from a zero vector with the quantised tables of
+//       its binade, exact arithmetic: traceback bytes for the whole chunk, the W rows at every 32nd
+//       position, the chunk minimum;
+//   FIX k_vit_fix                the exact sequential chain (same arithmetic as k_vit_coop) runs the
+//       first block of every chunk; at its 32nd step it compares V with the stored W row: if
+//       V - W is one constant, the binade matches and stays matched to the chunk end, the chain
+//       jumps to the next chunk with V = W_end + delta; otherwise it simply keeps going.
+// Exact rounding ties (b_t[j] an odd multiple of u/2: about one element in 2^(e-5)) are the one case
+// where fl(v + z) depends on the parity of v.  P2 does not model them: a position with a tie ends the
+// current speculative segment (its W row is recorded), the vector restarts from zeros behind it, and
+// the exact chain -- which always runs 64 exact positions after every jump -- lands exactly ON that
+// position.  A chunk is therefore a list of segments [tie, next tie).
+// The arg-max of P2 comes for free: the from-index is folded into six spare low bits of the
+// quantised transition table (values are re-based every 32 steps so they stay small).
+#pragma once
+#include "tehmm_coop.hip.h"
+
+namespace tehmm {
+
+#define TEHMM_SPEC_NONE (-2147483647 - 1)
+#define TEHMM_SPEC_MIN_E 18          // speculate only where |V| >= 2^18 (room for the index bits)
+
+struct VitChunks {
+  const int *iv;          // chunk -> interval id
+  const int64_t *t0;      // chunk -> first position (multiple of CS)
+  const int64_t *first;   // interval id -> index of its first chunk
+  int n;                  // number of chunks
+  int CS;                 // positions per chunk (multiple of 64)
+  const int *e;           // binade exponent the chunk is speculated in, or TEHMM_SPEC_NONE
+  double *gain;           // P0: max_j W_end of the chunk started from zeros
+  int *ok;                // P2: 1 = the speculative results of the chunk are usable
+  double *wmin;           // P2: most negative W (relative to the zero start) seen in the chunk
+  double *rows;           // P2: [chunk][CS/32][NT] W rows at positions t0 + 32k + 31
+  int *ntie;              // P2: number of tie positions in the chunk (> TEHMM_SPEC_MAXT: unusable)
+  int *ties;              // P2: [chunk][MAXT] tie positions relative to t0, ascending
+  double *tierows;        // P2: [chunk][MAXT][NT] W row of the position just before each tie
+};
+#define TEHMM_SPEC_MAXT 32
+
+// wave-wide max / min over the live lanes (fp64, shuffle based: used once per 32 steps)
+__device__ __forceinline__ double wave_max_live(double v, bool live) {
+  return wave_max_f64(live ? v : -INFINITY);
+}
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Speculative chunk pass.  blockDim = 256, every wave owns one chunk at a time (grid-stride).
+// Phases alternate inside the wave: 64 emission rows (lane = position) into its LDS ring, then 64
+// chain steps (lane = destination state, DPP row broadcast of the vector).
+// LDS (doubles): ring [4 waves][64][RS]
+// ------------------------------------------------------------------------------------------
+template <int NT, bool QUANT>
+__global__ __launch_bounds__(256) void k_vit_spec(IntervalTab iv, EmisTab em, VitChunks vc, int N,
+                                                  const double *g_lt, uint8_t *tb) {
+  extern __shared__ double sm[];
+  constexpr int RS = NT + 1;
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  double *ring = sm + w * 64 * RS;
+  volatile int *tieflag = (volatile int *)(sm + 4 * 64 * RS) + w * 64;   // per position of the block
+  const int jl = min(lane, NT - 1);
+  const bool live = lane < N;
+  for (int c = blockIdx.x * 4 + w; c < vc.n; c += gridDim.x * 4) {
+    const int e = QUANT ? vc.e[c] : 0;
+    if (QUANT && e == TEHMM_SPEC_NONE) continue;
+    const int id = vc.iv[c];
+    const int64_t T = iv.len[id];
+    const int64_t p0 = iv.pos0[id];
+    const int64_t t0 = vc.t0[c];
+    const int64_t t1 = min(T, t0 + vc.CS);
+    const double u = QUANT ? ldexp(1.0, e - 52) : 0.0;
+    const double M = QUANT ? ldexp(1.5, e) : 0.0;        // fl(z + M) - M rounds z to the grid u
+    const double half_u = 0.5 * u;
+    bool bad = false;
+    // column `lane` of the transition table, quantised and carrying the from-index in its low bits
+    double ltc[NT];
+#pragma unroll
+    for (int f = 0; f < NT; ++f) {
+      const double z = live ? g_lt[f * NT + jl] : -INFINITY;
+      if (QUANT) {
+        const double q = (z + M) - M;
+        if (fabs(z - q) == half_u) bad = true;            // exact tie: rounding would depend on V
+        ltc[f] = 64.0 * q + (double)(63 - f) * u;         // -inf stays -inf
+      } else {
+        ltc[f] = z;
+      }
+    }
+    double W = live ? 0.0 : -INFINITY;     // QUANT: 64 x (value - base); plain: value
+    double base = 0.0;                     // QUANT: multiple of u, sum of the re-basings
+    int nt = 0;                            // QUANT: tie positions found so far
+    for (int64_t tb0 = t0; tb0 < t1; tb0 += 64) {
+      const int np = (int)min((int64_t)64, t1 - tb0);
+      // ---- emission rows of this block (lane = position); the interval's first row is never in a
+      // speculated chunk, so the leading-rows quirk does not apply (seen = true)
+      {
+        const bool act = lane < np;
+        const int64_t gpos = p0 + tb0 + (act ? lane : np - 1);
+        double x[NT];
+        emis_rows<NT>(em, nullptr, gpos, x);
+        bool tie = false;
+        if (act) {
+          double *dst = ring + lane * RS;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            double b = x[j];
+            if (QUANT) {
+              const double q = (b + M) - M;
+              if (j < N && fabs(b - q) == half_u) tie = true;
+              b = 64.0 * q;
+            }
+            dst[j] = b;
+          }
+        }
+        if (QUANT) tieflag[lane] = tie ? 1 : 0;
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      // ---- chain steps
+      for (int p = 0; p < np; ++p) {
+        const int64_t t = tb0 + p;
+        const double b = ring[p * RS + jl];
+        double rr[(NT + 15) / 16];
+        rep_rows<NT>(W, rr);
+        double x[NT];
+        BcastAdd<0, NT>::run(rr, ltc, x);
+#pragma unroll
+        for (int n = NT; n > 1; n = (n + 1) / 2) {
+#pragma unroll
+          for (int i = 0; i < n / 2; ++i) x[i] = fmax(x[i], x[i + (n + 1) / 2]);
+        }
+        const double m = x[0];
+        if (QUANT) {
+          if (tieflag[p]) {
+            // a rounding tie at this position: close the segment (record W_{t-1}) and restart from
+            // zeros; the exact chain handles position t itself
+            if (nt < TEHMM_SPEC_MAXT) {
+              if (lane == 0) vc.ties[(int64_t)c * TEHMM_SPEC_MAXT + nt] = (int)(t - t0);
+              if (lane < NT)
+                vc.tierows[((int64_t)c * TEHMM_SPEC_MAXT + nt) * NT + lane] =
+                    live ? W * 0.015625 + base : -INFINITY;
+            }
+            ++nt;
+            W = live ? 0.0 : -INFINITY;
+            base = 0.0;
+          } else {
+            // m = 64 * (best value) + (63 - first arg-max) * u  (exact)
+            const double k = ldexp(m, 52 - e);                 // m / u, an integer
+            const double r = k - 64.0 * floor(k * 0.015625);   // k mod 64 in [0, 63]
+            const bool fin = m > -INFINITY;
+            const int arg = fin ? 63 - (int)r : 0;
+            W = fin ? (m - r * u) + b : -INFINITY;
+            if (live) tb[(p0 + t) * NT + lane] = (uint8_t)arg;
+          }
+          if ((p & 31) == 31) {
+            // re-base so that the index bits keep fitting, record the row
+            const double mx = wave_max_live(W, live);
+            if (mx > -INFINITY) {
+              W -= mx;
+              base += mx * 0.015625;
+            } else {
+              bad = true;                                    // the whole vector died
+            }
+            if (lane < NT)
+              vc.rows[((int64_t)c * (vc.CS / 32) + (t - t0) / 32) * NT + lane] =
+                  live ? W * 0.015625 + base : -INFINITY;
+          }
+        } else {
+          W = m + b;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (QUANT) {
+      const unsigned long long anybad = __ballot(bad);
+      if (lane == 0) {
+        vc.ntie[c] = nt;
+        vc.ok[c] = (anybad || nt > TEHMM_SPEC_MAXT) ? 0 : 1;
+      }
+    } else {
+      const double g = wave_max_live(W, live);
+      if (lane == 0) vc.gain[c] = g;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Exact sequential chain with jumps over verified chunks.  Same roles, rings and arithmetic as
+// k_vit_coop<NT, 64, false> (no segment ratios); the sequence of 64-position blocks is dynamic:
+//   seqpos[it & 3] = first position of the block of iteration `it` (>= T: finished), published by
+//   the chain wave at the 32nd step of the previous block (gen = it) so that the emission wave
+//   can prepare exactly that block.
+// LDS (doubles): bring [3][64][RS] | Vring [2][65][VS] | ltab [lds_rows][NT] | seq (4 x i64, gen)
+// ------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_lt,
+               const double *g_ltT, const double *g_pi, uint8_t *tb, int *last_state,
+               double *logprob, int *stats) {
+  extern __shared__ double sm[];
+  constexpr int RS = NT + 1;
+  constexpr int VS = NT + 2;
+  constexpr int CPB = 64;
+  double *bring = sm;
+  double *Vring = bring + 3 * CPB * RS;
+  double *ltab = Vring + 2 * (CPB + 1) * VS;
+  volatile int64_t *seqpos = (volatile int64_t *)(ltab + em.lds_rows * NT);
+  volatile int *gen = (volatile int *)(seqpos + 4);
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int id = iv.order[blockIdx.x];
+  const int64_t T = iv.len[id];
+  const int64_t p0 = iv.pos0[id];
+  if (T <= 0) return;
+  stage_emis_table(em, ltab, NT);
+  if (threadIdx.x == 0) {
+    seqpos[0] = 0;
+    seqpos[1] = seqpos[2] = seqpos[3] = T;
+    *gen = 0;
+  }
+  const int jl = min(lane, NT - 1);
+  const bool live = lane < N;
+  const int64_t cfirst = vc.first[id];
+  __syncthreads();
+  bool seen = false;     // leading-rows quirk state of the emission wave (_emission.pyx:73-80)
+  if (w == 1)            // prologue: emission rows of block 0
+    emis_block<NT, false, true, false>(em, ltab, p0, (int)min((int64_t)CPB, T), lane, N, seen, nullptr,
+                                       nullptr, nullptr, bring, RS, nullptr);
+  __syncthreads();
+  if (w == 0) {
+    // ============================================================== value chain
+    double ltc[NT];
+#pragma unroll
+    for (int f = 0; f < NT; ++f) ltc[f] = live ? g_lt[f * NT + jl] : -INFINITY;
+    const double pij = live ? g_pi[jl] : -INFINITY;
+    const int vslot = lane < NT ? lane : NT + 1;
+    double vcur = -INFINITY;
+    int n_jump = 0, n_block = 0;
+    for (int it = 0;; ++it) {
+      const int64_t cur = seqpos[it & 3];
+      const int64_t prev = it > 0 ? seqpos[(it - 1) & 3] : T;
+      if (cur >= T && prev >= T) break;
+      if (cur < T) {
+        ++n_block;
+        const int np = (int)min((int64_t)CPB, T - cur);
+        double *Vr = Vring + (it & 1) * (CPB + 1) * VS;
+        const double *br = bring + (it % 3) * CPB * RS;
+        if (cur > 0) Vr[vslot] = vcur;
+        // chunk of this block and whether it can be verified against the speculative pass:
+        // check row g = first recorded row (positions t0 + 32k + 31) at least 16 steps into the block;
+        // jump target = next tie position behind g (its predecessor's W row was recorded) or the
+        // chunk end.
+        const int64_t c = cfirst + cur / vc.CS;
+        const int64_t ct0 = vc.t0[c];
+        const int e = vc.e[c];
+        bool spec = e != TEHMM_SPEC_NONE && np == CPB && vc.ok[c] != 0;
+        const int64_t g = ct0 + ((cur + 16 - ct0) / 32) * 32 + 31;   // smallest recorded row >= cur + 16
+        const int pg = (int)(g - cur);                          // in-block step of the check, 16..47
+        int64_t target = ct0 + vc.CS;
+        const double *trow = vc.rows + ((c * (vc.CS / 32)) + (vc.CS / 32 - 1)) * NT;
+        if (spec) {
+          const int ntie = vc.ntie[c];
+          const int *tl = vc.ties + c * TEHMM_SPEC_MAXT;
+          for (int k = 0; k < ntie; ++k) {
+            const int64_t tp = ct0 + tl[k];
+            if (tp > g) { target = tp; trow = vc.tierows + (c * TEHMM_SPEC_MAXT + k) * NT; break; }
+          }
+          if (pg > 47 || g >= ct0 + vc.CS || target <= cur + CPB) spec = false;
+        }
+        double wrow = 0.0, wend = 0.0, delta = 0.0;
+        bool jump = false;
+        if (spec) {
+          wrow = vc.rows[((c * (vc.CS / 32)) + (g - ct0) / 32) * NT + jl];
+          wend = trow[jl];
+        } else {
+          if (lane == 0) { seqpos[(it + 1) & 3] = cur + np; *gen = it + 1; }
+        }
+        const double span = spec ? fabs(vc.gain[c]) * 1.01 + 256.0 : 0.0;
+        for (int p = 0; p < np; ++p) {
+          const int64_t t = cur + p;
+          const double b = br[p * RS + jl];
+          double v;
+          if (t == 0) {
+            v = pij + b;
+          } else {
+            double rr[(NT + 15) / 16];
+            rep_rows<NT>(vcur, rr);
+            double x[NT];
+            BcastAdd<0, NT>::run(rr, ltc, x);
+            const double c0 = x[0] + b;
+            x[0] = -INFINITY;
+#pragma unroll
+            for (int n = NT; n > 1; n = (n + 1) / 2) {
+#pragma unroll
+              for (int i = 0; i < n / 2; ++i) x[i] = fmax(x[i], x[i + (n + 1) / 2]);
+            }
+            const double c1 = x[0] + b;
+            v = c1 > c0 ? c1 : c0;
+          }
+          vcur = v;
+          Vr[(p + 1) * VS + vslot] = v;
+          if (spec && p == pg) {
+            // verified iff V - W is one constant over the live states, every V is in the binade the
+            // chunk was quantised for, and stays in it up to the chunk end
+            const double d = v - wrow;
+            const bool both_dead = v == -INFINITY && wrow == -INFINITY;
+            const double d0 = wave_max_live(both_dead ? -INFINITY : d, live);
+            const bool same = !live || both_dead || d == d0;
+            const bool inb = !live || both_dead || exp_of(-v) == e + 1;   // 2^e <= |v| < 2^(e+1)
+            const double vlow = wave_min_f64(live && !both_dead ? v : 0.0) - span;
+            const bool endok = d0 == d0 && d0 > -INFINITY && exp_of(-vlow) == e + 1;
+            jump = __all(same && inb) && endok;
+            delta = d0;
+            if (lane == 0) { seqpos[(it + 1) & 3] = jump ? target : cur + np; *gen = it + 1; }
+          }
+        }
+        if (jump) {
+          vcur = wend + delta;          // V at position target - 1 (exact: both multiples of u)
+          ++n_jump;
+        }
+      } else {
+        if (lane == 0) { seqpos[(it + 1) & 3] = T; *gen = it + 1; }
+      }
+      __syncthreads();
+    }
+    double *scratch = Vring;
+    if (lane < NT) scratch[lane] = vcur;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      int last = 0;
+      double m = scratch[0];
+      if (m == m) {
+        for (int j = 1; j < N; ++j) {
+          double x = scratch[j];
+          if (x != x) { last = j; break; }
+          if (x > m) { m = x; last = j; }
+        }
+      }
+      last_state[id] = last;
+      logprob[id] = scratch[last];
+      if (stats) { atomicAdd(&stats[0], n_block); atomicAdd(&stats[1], n_jump); }
+    }
+  } else if (w == 1) {
+    // ============================================================== emission rows of the NEXT block
+    for (int it = 0;; ++it) {
+      const int64_t cur = seqpos[it & 3];
+      const int64_t prev = it > 0 ? seqpos[(it - 1) & 3] : T;
+      if (cur >= T && prev >= T) break;
+      int spins = 0;
+      while (*gen < it + 1) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1 << 26)) break;      // never expected; bounded so that the grid drains
+      }
+      const int64_t nx = seqpos[(it + 1) & 3];
+      if (nx < T) {
+        const int np = (int)min((int64_t)CPB, T - nx);
+        emis_block<NT, false, true, false>(em, ltab, p0 + nx, np, lane, N, seen, nullptr, nullptr,
+                                           nullptr, bring + ((it + 1) % 3) * CPB * RS, RS, nullptr);
+      }
+      __syncthreads();
+    }
+  } else {
+    // ============================================================== exact arg-max of the PREVIOUS block
+    const int half = (N + 1) / 2;
+    const int to_lo = (w - 2) * half, to_hi = min(N, to_lo + half);
+    for (int it = 0;; ++it) {
+      const int64_t cur = seqpos[it & 3];
+      const int64_t prev = it > 0 ? seqpos[(it - 1) & 3] : T;
+      if (cur >= T && prev >= T) break;
+      if (it > 0 && prev < T) {
+        const int np = (int)min((int64_t)CPB, T - prev);
+        const double *Vr = Vring + ((it - 1) & 1) * (CPB + 1) * VS;
+        const double *br = bring + ((it - 1) % 3) * CPB * RS;
+        const int pl = lane < np ? lane : 0;
+        const int64_t t = prev + pl;
+        const bool actp = lane < np && t > 0;
+        lds_cd2 *vp = lds_row(Vr + pl * VS);
+        d2v pv[NT / 2];
+#pragma unroll
+        for (int f2 = 0; f2 < NT / 2; ++f2) pv[f2] = vp[f2];
+        const double *vnext = Vr + (pl + 1) * VS;
+        const double *brow = br + pl * RS;
+        for (int to = to_lo; to < to_hi; ++to) {
+          const double *lc = g_ltT + to * NT;
+          const double vt = vnext[to];
+          const double b = brow[to];
+          double c[NT];
+#pragma unroll
+          for (int f2 = 0; f2 < NT / 2; ++f2) {
+            c[2 * f2] = (pv[f2].x + lc[2 * f2]) + b;
+            c[2 * f2 + 1] = (pv[f2].y + lc[2 * f2 + 1]) + b;
+          }
+          int arg = 0;
+#pragma unroll
+          for (int f = NT - 1; f >= 1; --f) arg = c[f] == vt ? f : arg;
+          arg = c[0] == vt ? 0 : arg;
+          if (actp) tb[(p0 + t) * NT + to] = (uint8_t)arg;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+}  // namespace tehmm
