@@ -155,7 +155,8 @@ def main():
         #   viterbi: obs in (K) + int64 path out (8);  backward_posterior: obs in (K) + posterior
         #   row out (8N);  forward: obs in (K);  traceback: path out (8)
         alg = {"viterbi": K + 8, "backward_posterior": K + 8 * N, "forward": K, "traceback": 8,
-               "forward_backward": K, "posterior_combine": 8 * N}
+               "forward_backward": K, "posterior_combine": 8 * N, "viterbi_speculate": K,
+               "forward_backward_speculate": K + 16 * N}
         achieved = alg[dom] * float(total) / (kavg[dom] * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")

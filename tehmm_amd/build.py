@@ -11,8 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtehmm_hip.so")
 SOURCES = [os.path.join(CSRC, "tehmm_hip.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "tehmm_kernels.hip.h"), os.path.join(CSRC, "tehmm_coop.hip.h"),
-                  os.path.join(os.path.dirname(HERE), "include", "tehmm_hip.h")]
+DEPS = SOURCES + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [
+    os.path.join(os.path.dirname(HERE), "include", "tehmm_hip.h")]
 
 
 def hipcc():

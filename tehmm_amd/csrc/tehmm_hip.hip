@@ -112,7 +112,7 @@ struct SpecWork {
   std::vector<int64_t> h_t0, h_first;
   DBuf<int> iv, e, ok, stats, ntie, ties;
   DBuf<int64_t> t0, first;
-  DBuf<double> gain, wmin, rows, tierows;
+  DBuf<double> gain, wmin, rows, tierows, scale, wstart;
 };
 
 struct tehmm_batch {
@@ -141,7 +141,8 @@ struct tehmm_batch {
   DBuf<int> last_state;
   DBuf<double> vit_lp, fwd_lp;
   DBuf<int64_t> first_good;
-  hipStream_t sV = nullptr, sP = nullptr;
+  hipStream_t sV = nullptr, sP = nullptr, sB = nullptr;
+  hipEvent_t evX[2] = {nullptr, nullptr};
   hipEvent_t ev[16];
   int n_ev = 0;
   std::vector<std::string> tnames;
@@ -461,6 +462,9 @@ int tehmm_batch_create(int n, const int64_t *offsets, int K, const uint8_t *obs,
   }
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->sV, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->sP, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->sB, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&b->evX[0], hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&b->evX[1], hipEventDisableTiming);
   for (int i = 0; i < 16 && e == hipSuccess; ++i) {
     e = hipEventCreate(&b->ev[i]);
     if (e == hipSuccess) b->n_ev = i + 1;
@@ -478,6 +482,9 @@ int tehmm_batch_destroy(tehmm_batch_t *b) {
   for (int i = 0; i < b->n_ev; ++i) (void)hipEventDestroy(b->ev[i]);
   if (b->sV) (void)hipStreamDestroy(b->sV);
   if (b->sP) (void)hipStreamDestroy(b->sP);
+  if (b->sB) (void)hipStreamDestroy(b->sB);
+  for (int i = 0; i < 2; ++i)
+    if (b->evX[i]) (void)hipEventDestroy(b->evX[i]);
   delete b;
   return TEHMM_OK;
 }
@@ -636,7 +643,9 @@ static int spec_prepare(tehmm_batch *b, const tehmm_model *m, int CS) {
   HIPCHK(sw.first.upload(sw.h_first.data(), sw.h_first.size()));
   HIPCHK(sw.e.alloc(nc));
   HIPCHK(sw.ok.alloc(nc));
-  HIPCHK(sw.stats.alloc(4));
+  HIPCHK(sw.stats.alloc(8));
+  HIPCHK(sw.scale.alloc(nc * (size_t)(CS / 32)));
+  HIPCHK(sw.wstart.alloc(nc * (size_t)m->NP));
   HIPCHK(sw.gain.alloc(nc));
   HIPCHK(sw.wmin.alloc(nc));
   HIPCHK(sw.rows.alloc(nc * (size_t)(CS / 32) * m->NP));
@@ -696,6 +705,32 @@ static void launch_vit_fix(tehmm_batch *b, const tehmm_model *m, const IntervalT
                      m->pi.p, b->tb.p, b->last_state.p, b->vit_lp.p, b->sw.stats.p);
 }
 
+template <int NT>
+static void launch_fb_spec(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em,
+                           const FbChunks &fc, hipStream_t st) {
+  size_t lds = ((size_t)4 * 64 * (NT + 1) + 4 * 64) * sizeof(double);
+  const int grid = std::min((fc.n + 3) / 4, 4096);
+  allow_lds(k_fb_spec<NT, 0>, lds);
+  allow_lds(k_fb_spec<NT, 1>, lds);
+  hipLaunchKernelGGL((k_fb_spec<NT, 0>), dim3(grid), dim3(256), lds, st, iv, em, fc, m->N, m->A.p, b->post.p);
+  hipLaunchKernelGGL((k_fb_spec<NT, 1>), dim3(grid), dim3(256), lds, st, iv, em, fc, m->N, m->A.p, b->beta.p);
+}
+
+template <int NT>
+static void launch_fb_fix(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em_in,
+                          const FbChunks &fc, hipStream_t sF, hipStream_t sBk) {
+  const EmisTab em = b->n > 256 ? without_lds_tables(em_in) : em_in;
+  size_t lds = ((size_t)2 * 64 * (NT + 1) + 2 * 64 + NT + (size_t)em.lds_rows * NT + 8) * sizeof(double);
+  allow_lds(k_fb_fix<NT, 0, false>, lds);
+  allow_lds(k_fb_fix<NT, 1, false>, lds);
+  hipLaunchKernelGGL((k_fb_fix<NT, 0, false>), dim3(b->n), dim3(128), lds, sF, iv, em, fc, m->N, m->A.p,
+                     m->lt.p, m->pi.p, (const double *)nullptr, b->post.p, b->fwd_lp.p, b->dead.p,
+                     (double *)nullptr, (int *)nullptr, 1, b->sw.stats.p);
+  hipLaunchKernelGGL((k_fb_fix<NT, 1, false>), dim3(b->n), dim3(128), lds, sBk, iv, em, fc, m->N, m->A.p,
+                     m->lt.p, m->pi.p, (const double *)nullptr, b->beta.p, b->fwd_lp.p, b->dead.p,
+                     (double *)nullptr, (int *)nullptr, 1, b->sw.stats.p);
+}
+
 #define TEHMM_NT_DISPATCH(NP_, CALL)                                                                \
   switch (NP_) {                                                                                    \
     case 4: CALL(4); break;   case 8: CALL(8); break;   case 12: CALL(12); break;                   \
@@ -724,48 +759,97 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   fill_tabs(m, b, iv, em, false);   // decode / score_samples never apply ratios to emissions
   const int SPL = m->N <= 64 ? 1 : 2;
   const bool coop = m->N < 64;
-  int evi = 0;
-  if (flags & TEHMM_EVAL_VITERBI) {
+  // Enqueue order: Viterbi speculation pass 0 -> the whole posterior pipeline (async on its own
+  // streams) -> host binade assignment (needs pass 0) -> rest of the Viterbi pipeline.
+  const int CS = spec_chunk_size();
+  const bool spec_ok = coop && CS > 0 && m->NP <= 44 && b->total >= 2 * (int64_t)CS;
+  const bool vit = flags & TEHMM_EVAL_VITERBI, postr = flags & TEHMM_EVAL_POSTERIOR;
+  const bool vspec = vit && spec_ok && !ratio, fspec = postr && spec_ok;
+  if (vspec || fspec) {
+    rc = spec_prepare(b, m, CS);
+    if (rc) return rc;
+  }
+  SpecWork &sw = b->sw;
+  const EmisTab emg = without_lds_tables(em);
+  const int eV = 0, eP = 4;
+  VitChunks vc;
+  std::vector<double> gain;
+  if (vit) (void)hipEventRecord(b->ev[eV], b->sV);
+  if (vspec) {
+    // chunk-parallel exact Viterbi: P0 (plain gains) -> binades -> P2 (quantised) -> fix-up chain
     hipStream_t st = b->sV;
-    (void)hipEventRecord(b->ev[evi], st);
-    const int CS = spec_chunk_size();
-    bool spec_done = false;
-    if (coop && !ratio && CS > 0 && m->NP <= 44 && b->total >= 2 * (int64_t)CS) {
-      // chunk-parallel exact Viterbi: P0 (plain gains) -> binades -> P2 (quantised) -> fix-up chain
-      rc = spec_prepare(b, m, CS);
-      if (rc) return rc;
-      SpecWork &sw = b->sw;
-      VitChunks vc;
-      vc.iv = sw.iv.p; vc.t0 = sw.t0.p; vc.first = sw.first.p; vc.n = sw.n_chunks; vc.CS = CS;
-      vc.e = sw.e.p; vc.gain = sw.gain.p; vc.ok = sw.ok.p; vc.wmin = sw.wmin.p; vc.rows = sw.rows.p;
-      vc.ntie = sw.ntie.p; vc.ties = sw.ties.p; vc.tierows = sw.tierows.p;
-      const EmisTab emg = without_lds_tables(em);
+    vc.iv = sw.iv.p; vc.t0 = sw.t0.p; vc.first = sw.first.p; vc.n = sw.n_chunks; vc.CS = CS;
+    vc.e = sw.e.p; vc.gain = sw.gain.p; vc.ok = sw.ok.p; vc.wmin = sw.wmin.p; vc.rows = sw.rows.p;
+    vc.ntie = sw.ntie.p; vc.ties = sw.ties.p; vc.tierows = sw.tierows.p;
 #define CALL(NT_) launch_vit_spec<NT_>(b, m, iv, emg, vc, false, st)
+    TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+    gain.resize((size_t)std::max(1, sw.n_chunks));
+    HIPCHK(hipMemcpyAsync(gain.data(), sw.gain.p, gain.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
+  if (postr) {
+    hipStream_t st = b->sP;
+    (void)hipEventRecord(b->ev[eP], st);
+    if (fspec) {
+      // chunk-parallel forward / backward: speculative rows from uniform starts, then the two
+      // sequential chains (forward on this stream, backward on its own) with verified jumps
+      FbChunks fc;
+      fc.iv = sw.iv.p; fc.t0 = sw.t0.p; fc.first = sw.first.p; fc.n = sw.n_chunks; fc.CS = CS;
+      fc.scale = sw.scale.p; fc.wstart = sw.wstart.p;
+      (void)hipMemsetAsync(b->dead.p, 0, (size_t)(b->n + 1) * sizeof(int), st);
+      (void)hipMemsetAsync(sw.stats.p + 2, 0, 4 * sizeof(int), st);
+#define CALL(NT_) launch_fb_spec<NT_>(b, m, iv, emg, fc, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
-      std::vector<double> gain((size_t)std::max(1, sw.n_chunks));
-      HIPCHK(hipMemcpyAsync(gain.data(), sw.gain.p, gain.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      (void)hipEventRecord(b->ev[eP + 3], st);
+      (void)hipStreamWaitEvent(b->sB, b->ev[eP + 3], 0);
+#define CALL(NT_) launch_fb_fix<NT_>(b, m, iv, em, fc, st, b->sB)
+      TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+      (void)hipEventRecord(b->evX[1], b->sB);
+      (void)hipStreamWaitEvent(st, b->evX[1], 0);
+      (void)hipEventRecord(b->ev[eP + 1], st);
+      hipLaunchKernelGGL((k_combine<true>), dim3(grid_for(b->total * 16, 256, 256 * 16)), dim3(256), 0, st,
+                         b->total, m->N, b->post.p, b->beta.p);
+      hipLaunchKernelGGL(k_poison_dead, dim3(64, std::min(b->n, 1024)), dim3(256), 0, st, iv, b->dead.p, m->N,
+                         b->post.p, b->fwd_lp.p);
+    } else if (coop) {
+      (void)hipMemsetAsync(b->dead.p, 0, (size_t)(b->n + 1) * sizeof(int), st);
+#define CALL(NT_) launch_fb_coop<NT_>(b, m, iv, em, st)
+      TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+      (void)hipEventRecord(b->ev[eP + 1], st);
+      hipLaunchKernelGGL((k_combine<true>), dim3(grid_for(b->total * 16, 256, 256 * 16)), dim3(256), 0, st,
+                         b->total, m->N, b->post.p, b->beta.p);
+      hipLaunchKernelGGL(k_poison_dead, dim3(64, std::min(b->n, 1024)), dim3(256), 0, st, iv, b->dead.p, m->N, b->post.p,
+                         b->fwd_lp.p);
+    } else if (SPL == 1) launch_posterior<1>(b, m, iv, em, st, b->ev[eP + 1]);
+    else launch_posterior<2>(b, m, iv, em, st, b->ev[eP + 1]);
+    (void)hipEventRecord(b->ev[eP + 2], st);
+  }
+  if (vit) {
+    hipStream_t st = b->sV;
+    if (vspec) {
       HIPCHK(hipStreamSynchronize(st));
       std::vector<int> he;
       spec_assign_binades(b, gain, he);
       HIPCHK(hipMemcpyAsync(sw.e.p, he.data(), he.size() * sizeof(int), hipMemcpyHostToDevice, st));
       HIPCHK(hipMemsetAsync(sw.ok.p, 0, he.size() * sizeof(int), st));
-      HIPCHK(hipMemsetAsync(sw.stats.p, 0, 4 * sizeof(int), st));
+      HIPCHK(hipMemsetAsync(sw.stats.p, 0, 2 * sizeof(int), st));
 #define CALL(NT_) launch_vit_spec<NT_>(b, m, iv, emg, vc, true, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
-      (void)hipEventRecord(b->ev[evi + 3], st);
+      (void)hipEventRecord(b->ev[eV + 3], st);
 #define CALL(NT_) launch_vit_fix<NT_>(b, m, iv, em, vc, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
-      spec_done = true;
     } else if (coop) {
 #define CALL(NT_) launch_vit_coop<NT_>(b, m, iv, em, ratio, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
     } else if (SPL == 1) launch_viterbi<1>(b, m, iv, em, ratio, st);
     else launch_viterbi<2>(b, m, iv, em, ratio, st);
-    (void)hipEventRecord(b->ev[evi + 1], st);
+    (void)hipEventRecord(b->ev[eV + 1], st);
     if (b->n_chunks > 0)
       hipLaunchKernelGGL(k_tb_compose, dim3(b->n_chunks), dim3(64), 0, st, iv, b->d_chunk_iv.p,
                          b->d_chunk0.p, m->N, m->NP, b->TBW, b->tb.p, b->G.p);
@@ -775,41 +859,31 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       hipLaunchKernelGGL(k_tb_fill, dim3(grid_for(b->n_chunks, 64, 1 << 30)), dim3(64), 0, st, iv,
                          b->n_chunks, b->d_chunk_iv.p, b->d_chunk0.p, b->TBW, b->tb.p, b->bstate.p,
                          b->paths.p);
-    (void)hipEventRecord(b->ev[evi + 2], st);
-    if (spec_done) {
+    (void)hipEventRecord(b->ev[eV + 2], st);
+    if (vspec) {
       b->tnames.push_back("viterbi_speculate");
-      b->tpairs.push_back({evi, evi + 3});
+      b->tpairs.push_back({eV, eV + 3});
       b->tnames.push_back("viterbi");
-      b->tpairs.push_back({evi + 3, evi + 1});
+      b->tpairs.push_back({eV + 3, eV + 1});
     } else {
       b->tnames.push_back("viterbi");
-      b->tpairs.push_back({evi, evi + 1});
+      b->tpairs.push_back({eV, eV + 1});
     }
     b->tnames.push_back("traceback");
-    b->tpairs.push_back({evi + 1, evi + 2});
-    evi += 4;
+    b->tpairs.push_back({eV + 1, eV + 2});
   }
-  if (flags & TEHMM_EVAL_POSTERIOR) {
-    hipStream_t st = b->sP;
-    (void)hipEventRecord(b->ev[evi], st);
-    if (coop) {
-      (void)hipMemsetAsync(b->dead.p, 0, (size_t)(b->n + 1) * sizeof(int), st);
-#define CALL(NT_) launch_fb_coop<NT_>(b, m, iv, em, st)
-      TEHMM_NT_DISPATCH(m->NP, CALL)
-#undef CALL
-      (void)hipEventRecord(b->ev[evi + 1], st);
-      hipLaunchKernelGGL((k_combine<true>), dim3(grid_for(b->total * 16, 256, 256 * 16)), dim3(256), 0, st,
-                         b->total, m->N, b->post.p, b->beta.p);
-      hipLaunchKernelGGL(k_poison_dead, dim3(64, std::min(b->n, 1024)), dim3(256), 0, st, iv, b->dead.p, m->N, b->post.p,
-                         b->fwd_lp.p);
-    } else if (SPL == 1) launch_posterior<1>(b, m, iv, em, st, b->ev[evi + 1]);
-    else launch_posterior<2>(b, m, iv, em, st, b->ev[evi + 1]);
-    (void)hipEventRecord(b->ev[evi + 2], st);
-    b->tnames.push_back(coop ? "forward_backward" : "forward");
-    b->tpairs.push_back({evi, evi + 1});
+  if (postr) {
+    if (fspec) {
+      b->tnames.push_back("forward_backward_speculate");
+      b->tpairs.push_back({eP, eP + 3});
+      b->tnames.push_back("forward_backward");
+      b->tpairs.push_back({eP + 3, eP + 1});
+    } else {
+      b->tnames.push_back(coop ? "forward_backward" : "forward");
+      b->tpairs.push_back({eP, eP + 1});
+    }
     b->tnames.push_back(coop ? "posterior_combine" : "backward_posterior");
-    b->tpairs.push_back({evi + 1, evi + 2});
-    evi += 3;
+    b->tpairs.push_back({eP + 1, eP + 2});
   }
   HIPCHK(hipGetLastError());
   if (flags & TEHMM_EVAL_VITERBI) HIPCHK(hipStreamSynchronize(b->sV));
@@ -819,8 +893,19 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     (void)hipEventElapsedTime(&ms, b->ev[pr.first], b->ev[pr.second]);
     b->tms.push_back((double)ms);
   }
-  if ((flags & TEHMM_EVAL_VITERBI) && b->sw.stats.p && !b->tnames.empty() &&
-      b->tnames[0] == "viterbi_speculate") {
+  if (fspec) {
+    int st[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(st, b->sw.stats.p + 2, sizeof(st), hipMemcpyDeviceToHost));
+    b->tnames.push_back("count:forward_exact_blocks");
+    b->tms.push_back((double)st[0]);
+    b->tnames.push_back("count:forward_chunk_jumps");
+    b->tms.push_back((double)st[1]);
+    b->tnames.push_back("count:backward_exact_blocks");
+    b->tms.push_back((double)st[2]);
+    b->tnames.push_back("count:backward_chunk_jumps");
+    b->tms.push_back((double)st[3]);
+  }
+  if (vspec) {
     // counters (not times): 64-position blocks the exact chain ran / chunks it could jump over
     int st[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpy(st, b->sw.stats.p, sizeof(st), hipMemcpyDeviceToHost));

@@ -422,4 +422,311 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
   }
 }
 
+
+// ==========================================================================================
+// Chunk-parallel forward / backward (scaled linear domain, tolerance 1e-6 on posteriors).
+//
+// The normalised forward (backward) vector forgets its starting point: a positive linear map never
+// increases Hilbert's projective distance and these chains contract it by ~0.4 per step (measured:
+// 1e-12 within 20-50 steps on the bench model).  So every chunk is first run from a UNIFORM vector
+// (k_fb_spec, all chunks in parallel, rows written straight into the alpha / beta buffers), then
+// the sequential chain (k_fb_fix) runs 64-position blocks exactly (overwriting those rows) and, at
+// the 32nd step of each block, measures the projective distance between its vector and the
+// speculative row: below 1e-10 it adopts the speculative row at the chunk end and jumps -- every
+// later row of the chunk is then at least that close in direction, and posteriors only depend on
+// directions (k_combine normalises each row).  The forward log-likelihood is carried across a jump
+// by the speculative pass's own cumulative log-scale: S_end = S_g + log(rho) + (s'_end - s'_g).
+// ==========================================================================================
+struct FbChunks {
+  const int *iv;          // chunk -> interval id
+  const int64_t *t0;      // chunk -> first position
+  const int64_t *first;   // interval id -> index of its first chunk
+  int n, CS;
+  double *scale;          // forward spec: [chunk][CS/32] cumulative log-scale at positions t0+32k+31
+  double *wstart;         // backward spec: [chunk][NT] w row (bh' * beta) at the chunk's first position
+};
+#define TEHMM_FB_TOL 1e-10
+
+// Hilbert projective distance (as max/min ratio - 1) between two non-negative vectors over the live
+// lanes; returns a huge value when their supports differ or anything is not finite.  rho = the ratio
+// a / b at the lane where it is largest.
+__device__ __forceinline__ double proj_dist(double a, double b, bool live, double &rho) {
+  const bool both0 = a == 0.0 && b == 0.0;
+  const bool okl = !live || both0 || (a > 0.0 && b > 0.0 && a < INFINITY && b < INFINITY);
+  const double r = (live && !both0 && okl) ? a / b : -1.0;
+  const double rmax = wave_max_f64(r);
+  const double rmin = wave_min_f64(r < 0.0 ? INFINITY : r);
+  rho = rmax;
+  if (!__all(okl) || !(rmax > 0.0) || !(rmin < INFINITY)) return INFINITY;
+  return rmax / rmin - 1.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Speculative pass.  DIR = 0 forward (alpha rows + scale records), DIR = 1 backward (beta rows +
+// the w row at the chunk start).  blockDim = 256, one chunk per wave at a time.
+// Forward speculates chunks 1.. (chunk 0 starts from the true start vector in the fix-up chain),
+// backward speculates every chunk but the interval's last one; ragged tails are not speculated.
+// LDS (doubles): ring [4][64][RS] | ms [4][64]
+// ------------------------------------------------------------------------------------------
+template <int NT, int DIR>
+__global__ __launch_bounds__(256) void k_fb_spec(IntervalTab iv, EmisTab em, FbChunks fc, int N,
+                                                 const double *g_A, double *rows_out) {
+  extern __shared__ double sm[];
+  constexpr int RS = NT + 1;
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  double *ring = sm + w * 64 * RS;
+  double *ms = sm + 4 * 64 * RS + w * 64;
+  const int jl = min(lane, NT - 1);
+  const bool live = lane < N;
+  double ac[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+    ac[i] = live ? (DIR == 0 ? g_A[i * NT + jl] : g_A[jl * NT + i]) : (lane == NT - 1 ? 1.0 : 0.0);
+  for (int c = blockIdx.x * 4 + w; c < fc.n; c += gridDim.x * 4) {
+    const int id = fc.iv[c];
+    const int64_t T = iv.len[id];
+    const int64_t p0 = iv.pos0[id];
+    const int64_t t0 = fc.t0[c];
+    const int64_t t1 = t0 + fc.CS;
+    if (t1 > T) continue;                                   // ragged tail: sequential
+    if (DIR == 0 && c == fc.first[id]) continue;            // forward: first chunk is exact anyway
+    if (DIR == 1 && t1 >= T) continue;                      // backward: last chunk is exact anyway
+    double *out = rows_out + iv.out0[id] * N;
+    double v = live ? 1.0 / (double)N : 0.0;                // forward: a_{t0-1}; backward: w_{t1}
+    double s = 0.0;                                         // forward cumulative log-scale
+    bool seen = true;
+    if (DIR == 1) {
+      // w_{t1} = bh'_{t1} * 1: one emission row (position t1) through the ring
+      emis_block<NT, true, false, false>(em, nullptr, p0 + t1, 1, lane, N, seen, nullptr, nullptr, nullptr,
+                                         ring, RS, ms);
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      v = live ? ring[jl] : 0.0;
+      __builtin_amdgcn_wave_barrier();
+    }
+    for (int blk = 0; blk < fc.CS / 64; ++blk) {
+      const int64_t lo = DIR == 0 ? t0 + 64 * blk : t1 - 64 * (blk + 1);
+      if (DIR == 0)
+        emis_block<NT, true, true, false>(em, nullptr, p0 + lo, 64, lane, N, seen, nullptr, nullptr, nullptr,
+                                          ring, RS, ms);
+      else
+        emis_block<NT, true, false, false>(em, nullptr, p0 + lo, 64, lane, N, seen, nullptr, nullptr,
+                                           nullptr, ring, RS, ms);
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      for (int q = 0; q < 64; ++q) {
+        const int p = DIR == 0 ? q : 63 - q;
+        const int64_t t = lo + p;
+        const double bh = ring[p * RS + jl];
+        double rr[(NT + 15) / 16];
+        rep_rows<NT>(v, rr);
+        double sacc[4] = {0.0, 0.0, 0.0, 0.0};
+        asm volatile("s_nop 1" ::: "memory");
+        BcastFma<0, NT>::run(rr, ac, sacc);
+        const double ssum = (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]);
+        const int e = ((__builtin_amdgcn_readlane(__double2hiint(ssum), NT - 1) >> 20) & 0x7ff) - 1022;
+        if (DIR == 0) {
+          v = live ? ldexp(ssum * bh, -e) : 0.0;            // a_t
+          s += (double)e * 0.6931471805599453 + ms[p];
+          if (live) out[t * N + lane] = v;
+          if ((p & 31) == 31 && lane == 0) fc.scale[(int64_t)c * (fc.CS / 32) + (t - t0) / 32] = s;
+        } else {
+          const double bt = live ? ldexp(ssum, -e) : 0.0;   // beta_t
+          if (live) out[t * N + lane] = bt;
+          v = live ? bh * bt : 0.0;                         // w_t
+          if (t == t0 && lane < NT) fc.wstart[(int64_t)c * NT + lane] = v;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Sequential chain with verified jumps.  blockDim = 128: wave 0 chain, wave 1 emission rows of the
+// next block (same publish / wait protocol as k_vit_fix).  DIR = 0 forward: seqpos = first position
+// of a block (ascending); DIR = 1 backward: seqpos = one past the LAST position of a block
+// (descending; <= 0: finished).
+// LDS (doubles): ring [2][64][RS] | ms [2][64] | ltd [NT] | ltab [lds_rows][NT] | seq
+// ------------------------------------------------------------------------------------------
+template <int NT, int DIR, bool TRATIO>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A, const double *g_lt,
+              const double *g_pi, const double *tratios, double *rows, double *fwd_logprob,
+              int *dead_flag, double *wrows, int *escale, int allow_jump, int *stats) {
+  extern __shared__ double sm[];
+  constexpr int RS = NT + 1;
+  constexpr int CPB = 64;
+  double *ring = sm;
+  double *msr = ring + 2 * CPB * RS;
+  double *ltdv = msr + 2 * CPB;
+  double *ltab = ltdv + NT;
+  volatile int64_t *seqpos = (volatile int64_t *)(ltab + em.lds_rows * NT);
+  volatile int *gen = (volatile int *)(seqpos + 4);
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int id = iv.order[blockIdx.x];
+  const int64_t T = iv.len[id];
+  const int64_t p0 = iv.pos0[id];
+  if (T <= 0) return;
+  const int jl = min(lane, NT - 1);
+  const bool live = lane < N;
+  if (threadIdx.x < NT) ltdv[threadIdx.x] = g_lt[threadIdx.x * NT + threadIdx.x];
+  stage_emis_table(em, ltab, NT);
+  // a block is identified by `key`: DIR 0 -> its first position, DIR 1 -> one past its last position
+  const int64_t END = DIR == 0 ? T : 0;
+  if (threadIdx.x == 0) {
+    seqpos[0] = DIR == 0 ? 0 : T;
+    seqpos[1] = seqpos[2] = seqpos[3] = END;
+    *gen = 0;
+  }
+  const int64_t cfirst = fc.first[id];
+  __syncthreads();
+  bool seen = false;
+  // blocks are aligned to multiples of 64 in both directions (the backward chain starts with the
+  // ragged piece [64*floor((T-1)/64), T)), so every block lies inside one chunk
+  auto block_lo = [&](int64_t key) { return DIR == 0 ? key : ((key - 1) / CPB) * CPB; };
+  auto block_np = [&](int64_t key) {
+    return (int)(DIR == 0 ? min((int64_t)CPB, T - key) : key - ((key - 1) / CPB) * CPB);
+  };
+  auto done = [&](int64_t key) { return DIR == 0 ? key >= T : key <= 0; };
+  auto emit = [&](int64_t key, int slot) {
+    const int64_t lo = block_lo(key);
+    const int np = block_np(key);
+    if (DIR == 0)
+      emis_block<NT, true, true, TRATIO>(em, ltab, p0 + lo, np, lane, N, seen, dead_flag + id, ltdv, tratios,
+                                         ring + slot * CPB * RS, RS, msr + slot * CPB);
+    else {
+      bool dummy = true;
+      emis_block<NT, true, false, TRATIO>(em, ltab, p0 + lo, np, lane, N, dummy, nullptr, ltdv, tratios,
+                                          ring + slot * CPB * RS, RS, msr + slot * CPB);
+    }
+  };
+  if (w == 1) emit(seqpos[0], 0);      // prologue: rows of the first block
+  __syncthreads();
+  if (w == 0) {
+    double ac[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+      ac[i] = live ? (DIR == 0 ? g_A[i * NT + jl] : g_A[jl * NT + i]) : (lane == NT - 1 ? 1.0 : 0.0);
+    double *out = rows + iv.out0[id] * N;
+    int *es = (DIR == 0 && escale) ? escale + iv.out0[id] : nullptr;
+    double *wr = (DIR == 1 && wrows) ? wrows + iv.out0[id] * N : nullptr;
+    double Ecum = 0.0, Mcum = 0.0;
+    double v = 0.0;          // forward: a_t;  backward: w_t = bh'_t * beta_t
+    int n_block = 0, n_jump = 0;
+    for (int it = 0;; ++it) {
+      const int64_t cur = seqpos[it & 3];
+      if (done(cur)) break;
+      ++n_block;
+      const int64_t lo = block_lo(cur);
+      const int np = block_np(cur);
+      const double *br = ring + (it & 1) * CPB * RS;
+      const double *mr = msr + (it & 1) * CPB;
+      // chunk of this block; every full block inside a speculated chunk (but the chunk's last one
+      // in chain direction) verifies at its 32nd step and may jump to the chunk end
+      const int64_t c = cfirst + lo / fc.CS;
+      const int64_t ct0 = fc.t0[c];
+      const bool cfull = ct0 + fc.CS <= T;
+      const bool spec = allow_jump && np == CPB && cfull &&
+                        (DIR == 0 ? (c != cfirst && lo + CPB < ct0 + fc.CS) : (ct0 + fc.CS < T && lo > ct0));
+      const int pg = DIR == 0 ? 31 : 32;                        // check step inside the block
+      const int64_t tg = DIR == 0 ? lo + pg : cur - 1 - pg;     // its position
+      const int64_t target = DIR == 0 ? ct0 + fc.CS : ct0;      // key of the block after a jump
+      double srow = 0.0;
+      if (spec) srow = live ? out[tg * N + lane] : 0.0;         // speculative row, before overwriting
+      else if (lane == 0) {
+        seqpos[(it + 1) & 3] = DIR == 0 ? cur + np : lo;
+        *gen = it + 1;
+      }
+      bool jump = false;
+      double Sg = 0.0, rho = 1.0;
+      for (int q = 0; q < np; ++q) {
+        const int p = DIR == 0 ? q : np - 1 - q;
+        const int64_t t = lo + p;
+        const double bh = br[p * RS + jl];
+        if (DIR == 0) {
+          Mcum += mr[p];
+          if (t == 0) {
+            v = live ? exp(g_pi[jl]) * bh : 0.0;
+          } else {
+            double rr[(NT + 15) / 16];
+            rep_rows<NT>(v, rr);
+            double sacc[4] = {0.0, 0.0, 0.0, 0.0};
+            asm volatile("s_nop 1" ::: "memory");
+            BcastFma<0, NT>::run(rr, ac, sacc);
+            const double ssum = (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]);
+            const int e = ((__builtin_amdgcn_readlane(__double2hiint(ssum), NT - 1) >> 20) & 0x7ff) - 1022;
+            v = live ? ldexp(ssum * bh, -e) : 0.0;
+            Ecum += (double)e;
+            if (es && lane == 0) es[t] = e;
+          }
+          if (live) out[t * N + lane] = v;
+        } else {
+          double bt;
+          if (t == T - 1) {
+            bt = live ? 1.0 : 0.0;
+          } else {
+            double rr[(NT + 15) / 16];
+            rep_rows<NT>(v, rr);
+            double sacc[4] = {0.0, 0.0, 0.0, 0.0};
+            asm volatile("s_nop 1" ::: "memory");
+            BcastFma<0, NT>::run(rr, ac, sacc);
+            const double ssum = (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]);
+            const int e = ((__builtin_amdgcn_readlane(__double2hiint(ssum), NT - 1) >> 20) & 0x7ff) - 1022;
+            bt = live ? ldexp(ssum, -e) : 0.0;
+          }
+          if (live) out[t * N + lane] = bt;
+          if (spec && q == pg) {
+            const double d = proj_dist(bt, srow, live, rho);
+            jump = d <= TEHMM_FB_TOL;
+            if (lane == 0) { seqpos[(it + 1) & 3] = jump ? target : lo; *gen = it + 1; }
+          }
+          v = live ? bh * bt : 0.0;
+          if (wr && live) wr[t * N + lane] = v;
+        }
+        if (DIR == 0 && spec && q == pg) {
+          const double d = proj_dist(v, srow, live, rho);
+          jump = d <= TEHMM_FB_TOL;
+          Sg = Ecum * 0.6931471805599453 + Mcum;
+          if (lane == 0) { seqpos[(it + 1) & 3] = jump ? target : cur + np; *gen = it + 1; }
+        }
+      }
+      if (jump) {
+        ++n_jump;
+        if (DIR == 0) {
+          // adopt the speculative row at the chunk end; carry the log-likelihood over the jump
+          const int64_t tl = target - 1;
+          v = live ? out[tl * N + lane] : 0.0;
+          const double *sc = fc.scale + c * (fc.CS / 32);
+          Mcum = Sg + log(rho) + (sc[fc.CS / 32 - 1] - sc[(tg - ct0) / 32]);
+          Ecum = 0.0;
+        } else {
+          v = live ? fc.wstart[c * NT + jl] : 0.0;
+        }
+      }
+      __syncthreads();
+    }
+    if (DIR == 0) {
+      const double tot = wave_sum_f64(live ? v : 0.0);
+      if (lane == 0) fwd_logprob[id] = log(tot) + Ecum * 0.6931471805599453 + Mcum;
+    }
+    if (stats && lane == 0) { atomicAdd(&stats[2 + 2 * DIR], n_block); atomicAdd(&stats[3 + 2 * DIR], n_jump); }
+  } else {
+    for (int it = 0;; ++it) {
+      const int64_t cur = seqpos[it & 3];
+      if (done(cur)) break;
+      int spins = 0;
+      while (*gen < it + 1) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1 << 26)) break;
+      }
+      const int64_t nx = seqpos[(it + 1) & 3];
+      if (!done(nx)) emit(nx, (it + 1) & 1);
+      __syncthreads();
+    }
+  }
+}
+
 }  // namespace tehmm
