@@ -2,7 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see tehmm_amd/build.py).
 #include "tehmm_kernels.hip.h"
 #include "tehmm_coop.hip.h"
-#include "tehmm_spec.hip.h"
+#include "tehmm_lane.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -115,9 +115,18 @@ struct SpecWork {
   DBuf<double> gain, wmin, rows, tierows, scale, wstart;
 };
 
+// item (sub-chunk) bookkeeping and item-interleaved buffers of the lane = item passes
+struct LaneWork {
+  int L = 0, CS = 0, NP = 0, n_items = 0, n_groups = 0;
+  DBuf<int> item_iv, ok_f, ok_b;
+  DBuf<int64_t> item_t0, ifirst;
+  DBuf<double> B, BH, MS, AL, BE, pre_f, end_f, pre_b, end_b, slog32;
+};
+
 struct tehmm_batch {
   EstepWork ew;
   SpecWork sw;
+  LaneWork lw;
   int n = 0, K = 0, KP = 0;
   int64_t total = 0;       // user rows
   int64_t total_pad = 0;   // internal positions (64-aligned per interval)
@@ -546,8 +555,12 @@ static int ensure_workspace(tehmm_batch *b, const tehmm_model *m, int flags) {
     HIPCHK(b->fwd_lp.alloc((size_t)b->n + 1));
     HIPCHK(b->first_good.alloc((size_t)b->n + 1));
     HIPCHK(b->dead.alloc((size_t)b->n + 1));
-    if (m->N < 64) HIPCHK(b->beta.alloc((size_t)b->total * m->N + 1));
   }
+  return TEHMM_OK;
+}
+
+static int ensure_beta(tehmm_batch *b, const tehmm_model *m) {
+  if (!b->beta.p) HIPCHK(b->beta.alloc((size_t)b->total * m->N + 1));
   return TEHMM_OK;
 }
 
@@ -705,6 +718,112 @@ static void launch_vit_fix(tehmm_batch *b, const tehmm_model *m, const IntervalT
                      m->pi.p, b->tb.p, b->last_state.p, b->vit_lp.p, b->sw.stats.p);
 }
 
+// ---- lane = item passes -----------------------------------------------------------------------
+static int lane_sub_size(int CS) {
+  const char *s = std::getenv("TEHMM_LANE_SUB");       // 0 disables; tests use small items
+  int L = s ? std::atoi(s) : 512;
+  if (L <= 0 || CS <= 0) return 0;
+  L = std::max(64, (L + 63) & ~63);
+  if (L > CS || CS % L != 0) L = CS;
+  return L;
+}
+
+static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, bool want_fb) {
+  LaneWork &lw = b->lw;
+  if (lw.L != L || lw.CS != CS || lw.NP != m->NP || !lw.item_iv.p) {
+    std::vector<int> h_iv;
+    std::vector<int64_t> h_t0, h_first((size_t)b->n + 1, 0);
+    for (int i = 0; i < b->n; ++i) {
+      h_first[i] = (int64_t)h_iv.size();
+      for (int64_t t0 = 0; t0 < b->h_len[i]; t0 += L) {
+        h_iv.push_back(i);
+        h_t0.push_back(t0);
+      }
+    }
+    h_first[b->n] = (int64_t)h_iv.size();
+    for (DBuf<double> *d : {&lw.B, &lw.BH, &lw.MS, &lw.AL, &lw.BE, &lw.pre_f, &lw.end_f, &lw.pre_b, &lw.end_b,
+                            &lw.slog32})
+      d->release();
+    lw.ok_f.release();
+    lw.ok_b.release();
+    lw.L = L; lw.CS = CS; lw.NP = m->NP;
+    lw.n_items = (int)h_iv.size();
+    lw.n_groups = (lw.n_items + 63) / 64;
+    HIPCHK(lw.item_iv.upload(h_iv.data(), h_iv.size()));
+    HIPCHK(lw.item_t0.upload(h_t0.data(), h_t0.size()));
+    HIPCHK(lw.ifirst.upload(h_first.data(), h_first.size()));
+  }
+  const size_t rows = (size_t)std::max(1, lw.n_groups) * L * 64;        // item-interleaved positions
+  const size_t vecs = (size_t)std::max(1, lw.n_groups) * 64 * m->NP;
+  if (want_fb && !lw.AL.p) {
+    HIPCHK(lw.BH.alloc(rows * m->NP));
+    HIPCHK(lw.MS.alloc(rows));
+    HIPCHK(lw.AL.alloc(rows * m->NP));
+    HIPCHK(lw.BE.alloc(rows * m->NP));
+    HIPCHK(lw.pre_f.alloc(vecs));
+    HIPCHK(lw.end_f.alloc(vecs));
+    HIPCHK(lw.pre_b.alloc(vecs));
+    HIPCHK(lw.end_b.alloc(vecs));
+    HIPCHK(lw.slog32.alloc((size_t)std::max(1, lw.n_groups) * 64 * (L / 32)));
+    HIPCHK(lw.ok_f.alloc((size_t)std::max(1, b->sw.n_chunks)));
+    HIPCHK(lw.ok_b.alloc((size_t)std::max(1, b->sw.n_chunks)));
+  }
+  return TEHMM_OK;
+}
+
+static LaneGeom lane_geom(const LaneWork &lw) {
+  LaneGeom lg;
+  lg.item_iv = lw.item_iv.p; lg.item_t0 = lw.item_t0.p; lg.ifirst = lw.ifirst.p;
+  lg.n_items = lw.n_items; lg.n_groups = lw.n_groups; lg.L = lw.L;
+  return lg;
+}
+
+template <int NT>
+static void launch_emis_lane(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em,
+                             bool want_log, bool want_lin, hipStream_t st) {
+  LaneWork &lw = b->lw;
+  hipLaunchKernelGGL((k_emis_lane<NT>), dim3((lw.n_groups + 3) / 4), dim3(256), 0, st, iv, em, lane_geom(lw),
+                     m->N, want_log ? lw.B.p : (double *)nullptr, want_lin ? lw.BH.p : (double *)nullptr, lw.MS.p);
+}
+
+template <int NT>
+static void launch_fb_lane(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const FbChunks &fc,
+                           int Wu, hipStream_t st) {
+  LaneWork &lw = b->lw;
+  const LaneGeom lg = lane_geom(lw);
+  const dim3 grid((lw.n_groups + 3) / 4);
+  hipLaunchKernelGGL((k_fb_lane<NT, 0>), grid, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->A.p, lw.BH.p,
+                     lw.MS.p, lw.AL.p, lw.pre_f.p, lw.end_f.p, lw.slog32.p);
+  hipLaunchKernelGGL((k_fb_lane<NT, 1>), grid, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->AT.p, lw.BH.p,
+                     lw.MS.p, lw.BE.p, lw.pre_b.p, lw.end_b.p, (double *)nullptr);
+  hipLaunchKernelGGL((k_fb_stitch<NT>), dim3((fc.n + 3) / 4), dim3(256), 0, st, iv, lg, fc, m->N, lw.pre_f.p,
+                     lw.end_f.p, lw.slog32.p, lw.pre_b.p, lw.end_b.p, lw.ok_f.p, lw.ok_b.p);
+}
+
+template <int NT>
+static void launch_fb_fix_lane(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em_in,
+                               const FbChunks &fc, hipStream_t sF, hipStream_t sBk) {
+  LaneWork &lw = b->lw;
+  const LaneGeom lg = lane_geom(lw);
+  const EmisTab em = b->n > 256 ? without_lds_tables(em_in) : em_in;
+  size_t lds = ((size_t)2 * 64 * (NT + 1) + 2 * 64 + NT + (size_t)em.lds_rows * NT + 8) * sizeof(double);
+  allow_lds(k_fb_fix<NT, 0, false, true>, lds);
+  allow_lds(k_fb_fix<NT, 1, false, true>, lds);
+  hipLaunchKernelGGL((k_fb_fix<NT, 0, false, true>), dim3(b->n), dim3(128), lds, sF, iv, em, fc, m->N, m->A.p,
+                     m->lt.p, m->pi.p, (const double *)nullptr, lw.AL.p, b->fwd_lp.p, b->dead.p,
+                     (double *)nullptr, (int *)nullptr, 1, b->sw.stats.p, lg, (const int *)lw.ok_f.p);
+  hipLaunchKernelGGL((k_fb_fix<NT, 1, false, true>), dim3(b->n), dim3(128), lds, sBk, iv, em, fc, m->N, m->A.p,
+                     m->lt.p, m->pi.p, (const double *)nullptr, lw.BE.p, b->fwd_lp.p, b->dead.p,
+                     (double *)nullptr, (int *)nullptr, 1, b->sw.stats.p, lg, (const int *)lw.ok_b.p);
+}
+
+template <int NT>
+static void launch_combine_lane(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, hipStream_t st) {
+  LaneWork &lw = b->lw;
+  hipLaunchKernelGGL((k_combine_lane<NT, true>), dim3((unsigned)lw.n_groups * (lw.L / 8)), dim3(256), 0, st, iv,
+                     lane_geom(lw), m->N, lw.AL.p, lw.BE.p, b->post.p);
+}
+
 template <int NT>
 static void launch_fb_spec(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em,
                            const FbChunks &fc, hipStream_t st) {
@@ -721,14 +840,14 @@ static void launch_fb_fix(tehmm_batch *b, const tehmm_model *m, const IntervalTa
                           const FbChunks &fc, hipStream_t sF, hipStream_t sBk) {
   const EmisTab em = b->n > 256 ? without_lds_tables(em_in) : em_in;
   size_t lds = ((size_t)2 * 64 * (NT + 1) + 2 * 64 + NT + (size_t)em.lds_rows * NT + 8) * sizeof(double);
-  allow_lds(k_fb_fix<NT, 0, false>, lds);
-  allow_lds(k_fb_fix<NT, 1, false>, lds);
-  hipLaunchKernelGGL((k_fb_fix<NT, 0, false>), dim3(b->n), dim3(128), lds, sF, iv, em, fc, m->N, m->A.p,
+  allow_lds(k_fb_fix<NT, 0, false, false>, lds);
+  allow_lds(k_fb_fix<NT, 1, false, false>, lds);
+  hipLaunchKernelGGL((k_fb_fix<NT, 0, false, false>), dim3(b->n), dim3(128), lds, sF, iv, em, fc, m->N, m->A.p,
                      m->lt.p, m->pi.p, (const double *)nullptr, b->post.p, b->fwd_lp.p, b->dead.p,
-                     (double *)nullptr, (int *)nullptr, 1, b->sw.stats.p);
-  hipLaunchKernelGGL((k_fb_fix<NT, 1, false>), dim3(b->n), dim3(128), lds, sBk, iv, em, fc, m->N, m->A.p,
+                     (double *)nullptr, (int *)nullptr, 1, b->sw.stats.p, LaneGeom(), (const int *)nullptr);
+  hipLaunchKernelGGL((k_fb_fix<NT, 1, false, false>), dim3(b->n), dim3(128), lds, sBk, iv, em, fc, m->N, m->A.p,
                      m->lt.p, m->pi.p, (const double *)nullptr, b->beta.p, b->fwd_lp.p, b->dead.p,
-                     (double *)nullptr, (int *)nullptr, 1, b->sw.stats.p);
+                     (double *)nullptr, (int *)nullptr, 1, b->sw.stats.p, LaneGeom(), (const int *)nullptr);
 }
 
 #define TEHMM_NT_DISPATCH(NP_, CALL)                                                                \
@@ -772,6 +891,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   SpecWork &sw = b->sw;
   const EmisTab emg = without_lds_tables(em);
   const int eV = 0, eP = 4;
+  bool flane = false;
   VitChunks vc;
   std::vector<double> gain;
   if (vit) (void)hipEventRecord(b->ev[eV], b->sV);
@@ -790,9 +910,45 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   if (postr) {
     hipStream_t st = b->sP;
     (void)hipEventRecord(b->ev[eP], st);
-    if (fspec) {
+    const int LS = fspec ? lane_sub_size(CS) : 0;
+    if (fspec && LS > 0) {
+      // lane = item passes (emission rows, forward, backward, links), then the two sequential chains
+      // on the item-interleaved rows, then the transposing combine
+      rc = lane_prepare(b, m, CS, LS, true);
+      if (rc) return rc;
+      FbChunks fc;
+      fc.iv = sw.iv.p; fc.t0 = sw.t0.p; fc.first = sw.first.p; fc.n = sw.n_chunks; fc.CS = CS;
+      fc.scale = sw.scale.p; fc.wstart = sw.wstart.p;
+      const char *wus = std::getenv("TEHMM_LANE_WARMUP");
+      const int Wu = std::min(LS, std::max(1, wus ? std::atoi(wus) : 96));
+      (void)hipMemsetAsync(b->dead.p, 0, (size_t)(b->n + 1) * sizeof(int), st);
+      (void)hipMemsetAsync(sw.stats.p + 2, 0, 4 * sizeof(int), st);
+#define CALL(NT_) launch_emis_lane<NT_>(b, m, iv, emg, false, true, st)
+      TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+      (void)hipEventRecord(b->ev[eP + 4], st);
+#define CALL(NT_) launch_fb_lane<NT_>(b, m, iv, fc, Wu, st)
+      TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+      (void)hipEventRecord(b->ev[eP + 3], st);
+      (void)hipStreamWaitEvent(b->sB, b->ev[eP + 3], 0);
+#define CALL(NT_) launch_fb_fix_lane<NT_>(b, m, iv, em, fc, st, b->sB)
+      TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+      (void)hipEventRecord(b->evX[1], b->sB);
+      (void)hipStreamWaitEvent(st, b->evX[1], 0);
+      (void)hipEventRecord(b->ev[eP + 1], st);
+#define CALL(NT_) launch_combine_lane<NT_>(b, m, iv, st)
+      TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+      hipLaunchKernelGGL(k_poison_dead, dim3(64, std::min(b->n, 1024)), dim3(256), 0, st, iv, b->dead.p, m->N,
+                         b->post.p, b->fwd_lp.p);
+      flane = true;
+    } else if (fspec) {
       // chunk-parallel forward / backward: speculative rows from uniform starts, then the two
       // sequential chains (forward on this stream, backward on its own) with verified jumps
+      rc = ensure_beta(b, m);
+      if (rc) return rc;
       FbChunks fc;
       fc.iv = sw.iv.p; fc.t0 = sw.t0.p; fc.first = sw.first.p; fc.n = sw.n_chunks; fc.CS = CS;
       fc.scale = sw.scale.p; fc.wstart = sw.wstart.p;
@@ -814,6 +970,8 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       hipLaunchKernelGGL(k_poison_dead, dim3(64, std::min(b->n, 1024)), dim3(256), 0, st, iv, b->dead.p, m->N,
                          b->post.p, b->fwd_lp.p);
     } else if (coop) {
+      rc = ensure_beta(b, m);
+      if (rc) return rc;
       (void)hipMemsetAsync(b->dead.p, 0, (size_t)(b->n + 1) * sizeof(int), st);
 #define CALL(NT_) launch_fb_coop<NT_>(b, m, iv, em, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
@@ -873,7 +1031,14 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     b->tpairs.push_back({eV + 1, eV + 2});
   }
   if (postr) {
-    if (fspec) {
+    if (flane) {
+      b->tnames.push_back("emission_rows");
+      b->tpairs.push_back({eP, eP + 4});
+      b->tnames.push_back("forward_backward_speculate");
+      b->tpairs.push_back({eP + 4, eP + 3});
+      b->tnames.push_back("forward_backward");
+      b->tpairs.push_back({eP + 3, eP + 1});
+    } else if (fspec) {
       b->tnames.push_back("forward_backward_speculate");
       b->tpairs.push_back({eP, eP + 3});
       b->tnames.push_back("forward_backward");

@@ -71,7 +71,7 @@ __device__ __forceinline__ double wave_min_f64(double v) {
 // LDS (doubles): ring [4 waves][64][RS]
 // ------------------------------------------------------------------------------------------
 template <int NT, bool QUANT>
-__global__ __launch_bounds__(256) void k_vit_spec(IntervalTab iv, EmisTab em, VitChunks vc, int N,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vit_spec(IntervalTab iv, EmisTab em, VitChunks vc, int N,
                                                   const double *g_lt, uint8_t *tb) {
   extern __shared__ double sm[];
   constexpr int RS = NT + 1;
@@ -447,6 +447,18 @@ struct FbChunks {
 };
 #define TEHMM_FB_TOL 1e-10
 
+// item (sub-chunk) geometry of the lane = item passes, see tehmm_lane.hip.h
+struct LaneGeom {
+  const int *item_iv;       // item -> interval id
+  const int64_t *item_t0;   // item -> first position inside the interval (multiple of L)
+  const int64_t *ifirst;    // interval id -> its first item
+  int n_items, n_groups, L;
+};
+// element (t_rel, state 0) of item `item` in an item-interleaved buffer; states are 64 doubles apart
+__device__ __forceinline__ int64_t lane_row(const LaneGeom &lg, int NT, int64_t item, int64_t trel) {
+  return ((((item >> 6) * lg.L + trel) * NT) << 6) + (item & 63);
+}
+
 // Hilbert projective distance (as max/min ratio - 1) between two non-negative vectors over the live
 // lanes; returns a huge value when their supports differ or anything is not finite.  rho = the ratio
 // a / b at the lane where it is largest.
@@ -469,7 +481,7 @@ __device__ __forceinline__ double proj_dist(double a, double b, bool live, doubl
 // LDS (doubles): ring [4][64][RS] | ms [4][64]
 // ------------------------------------------------------------------------------------------
 template <int NT, int DIR>
-__global__ __launch_bounds__(256) void k_fb_spec(IntervalTab iv, EmisTab em, FbChunks fc, int N,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_fb_spec(IntervalTab iv, EmisTab em, FbChunks fc, int N,
                                                  const double *g_A, double *rows_out) {
   extern __shared__ double sm[];
   constexpr int RS = NT + 1;
@@ -550,11 +562,14 @@ __global__ __launch_bounds__(256) void k_fb_spec(IntervalTab iv, EmisTab em, FbC
 // (descending; <= 0: finished).
 // LDS (doubles): ring [2][64][RS] | ms [2][64] | ltd [NT] | ltab [lds_rows][NT] | seq
 // ------------------------------------------------------------------------------------------
-template <int NT, int DIR, bool TRATIO>
+// LANE: `rows` is item-interleaved (tehmm_lane.hip.h) and okc[c] tells whether the chunk's item links
+// hold; otherwise rows is [T][N] as written by k_fb_spec.
+template <int NT, int DIR, bool TRATIO, bool LANE>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A, const double *g_lt,
               const double *g_pi, const double *tratios, double *rows, double *fwd_logprob,
-              int *dead_flag, double *wrows, int *escale, int allow_jump, int *stats) {
+              int *dead_flag, double *wrows, int *escale, int allow_jump, int *stats, LaneGeom lg,
+              const int *okc) {
   extern __shared__ double sm[];
   constexpr int RS = NT + 1;
   constexpr int CPB = 64;
@@ -610,7 +625,13 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
 #pragma unroll
     for (int i = 0; i < NT; ++i)
       ac[i] = live ? (DIR == 0 ? g_A[i * NT + jl] : g_A[jl * NT + i]) : (lane == NT - 1 ? 1.0 : 0.0);
-    double *out = rows + iv.out0[id] * N;
+    double *out = LANE ? rows : rows + iv.out0[id] * N;
+    const int64_t ifirst = LANE ? lg.ifirst[id] : 0;
+    // element of this lane in the row of position t
+    auto rowp = [&](int64_t t) -> double * {
+      if (LANE) return out + lane_row(lg, NT, ifirst + t / lg.L, t % lg.L) + ((int64_t)jl << 6);
+      return out + t * N + lane;
+    };
     int *es = (DIR == 0 && escale) ? escale + iv.out0[id] : nullptr;
     double *wr = (DIR == 1 && wrows) ? wrows + iv.out0[id] * N : nullptr;
     double Ecum = 0.0, Mcum = 0.0;
@@ -629,13 +650,15 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
       const int64_t c = cfirst + lo / fc.CS;
       const int64_t ct0 = fc.t0[c];
       const bool cfull = ct0 + fc.CS <= T;
-      const bool spec = allow_jump && np == CPB && cfull &&
+      const bool spec = allow_jump && np == CPB && cfull && (!LANE || okc[c] != 0) &&
                         (DIR == 0 ? (c != cfirst && lo + CPB < ct0 + fc.CS) : (ct0 + fc.CS < T && lo > ct0));
+      double *brow = rowp(lo);                                  // row of position lo (blocks never straddle items)
+      const int64_t rstride = LANE ? (int64_t)NT << 6 : (int64_t)N;
       const int pg = DIR == 0 ? 31 : 32;                        // check step inside the block
       const int64_t tg = DIR == 0 ? lo + pg : cur - 1 - pg;     // its position
       const int64_t target = DIR == 0 ? ct0 + fc.CS : ct0;      // key of the block after a jump
       double srow = 0.0;
-      if (spec) srow = live ? out[tg * N + lane] : 0.0;         // speculative row, before overwriting
+      if (spec) srow = live ? brow[(tg - lo) * rstride] : 0.0;  // speculative row, before overwriting
       else if (lane == 0) {
         seqpos[(it + 1) & 3] = DIR == 0 ? cur + np : lo;
         *gen = it + 1;
@@ -662,7 +685,7 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
             Ecum += (double)e;
             if (es && lane == 0) es[t] = e;
           }
-          if (live) out[t * N + lane] = v;
+          if (live) brow[p * rstride] = v;
         } else {
           double bt;
           if (t == T - 1) {
@@ -677,7 +700,7 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
             const int e = ((__builtin_amdgcn_readlane(__double2hiint(ssum), NT - 1) >> 20) & 0x7ff) - 1022;
             bt = live ? ldexp(ssum, -e) : 0.0;
           }
-          if (live) out[t * N + lane] = bt;
+          if (live) brow[p * rstride] = bt;
           if (spec && q == pg) {
             const double d = proj_dist(bt, srow, live, rho);
             jump = d <= TEHMM_FB_TOL;
@@ -698,7 +721,7 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
         if (DIR == 0) {
           // adopt the speculative row at the chunk end; carry the log-likelihood over the jump
           const int64_t tl = target - 1;
-          v = live ? out[tl * N + lane] : 0.0;
+          v = live ? *rowp(tl) : 0.0;
           const double *sc = fc.scale + c * (fc.CS / 32);
           Mcum = Sg + log(rho) + (sc[fc.CS / 32 - 1] - sc[(tg - ct0) / 32]);
           Ecum = 0.0;

@@ -160,9 +160,10 @@ def test_fused_batch_ragged(hip, N, with_ratio):
     assert_allclose(post, post_o, rtol=RTOL, atol=1e-15)
     assert_allclose(post.sum(axis=1), 1.0, rtol=1e-9)
     t = hb.timing()
-    names = {k for k in t if not k.startswith("count:")} - {"viterbi_speculate", "forward_backward_speculate"}
-    assert names in ({"viterbi", "traceback", "forward", "backward_posterior"},
-                     {"viterbi", "traceback", "forward_backward", "posterior_combine"})
+    names = {k for k in t if not k.startswith("count:")}
+    assert {"viterbi", "traceback"} <= names
+    assert ({"forward", "backward_posterior"} <= names) or ({"forward_backward", "posterior_combine"} <= names)
+    assert all(v >= 0.0 for v in t.values())
 
 
 @pytest.mark.parametrize("N,with_ratio", [(35, 0), (35, 1), (6, 1), (20, 0)])
