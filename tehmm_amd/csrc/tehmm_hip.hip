@@ -1,5 +1,6 @@
 // tehmm_hip.hip -- host side of libtehmm_hip.so: the C ABI declared in include/tehmm_hip.h.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see tehmm_amd/build.py).
+#include <climits>
 #include "tehmm_kernels.hip.h"
 #include "tehmm_coop.hip.h"
 #include "tehmm_lane.hip.h"
@@ -89,6 +90,7 @@ struct tehmm_model {
   int N = 0, NP = 0, K = 0, S = 0, R = 0;
   double normalize = 1.0;
   DBuf<double> lt, ltT, A, AT, pi, tab, ltab;
+  DBuf<double> ltG, AG, ATG;   // output-group-major copies for the lane = item kernels (tehmm_lane.hip.h)
   int rowbase[TEHMM_MAX_TRACKS];
   int rowcnt[TEHMM_MAX_TRACKS];
   int ldsbase[TEHMM_MAX_TRACKS];
@@ -112,15 +114,21 @@ struct SpecWork {
   std::vector<int64_t> h_t0, h_first;
   DBuf<int> iv, e, ok, stats, ntie, ties;
   DBuf<int64_t> t0, first;
-  DBuf<double> gain, wmin, rows, tierows, scale, wstart;
+  DBuf<double> gain, wmin, rows, tierows, scale, wstart, segmin;
 };
 
 // item (sub-chunk) bookkeeping and item-interleaved buffers of the lane = item passes
 struct LaneWork {
   int L = 0, CS = 0, NP = 0, n_items = 0, n_groups = 0;
+  std::vector<int> h_iv;
+  std::vector<int64_t> h_t0, h_first;
+  int64_t h_first_item(int id) const { return h_first[(size_t)id]; }
   DBuf<int> item_iv, ok_f, ok_b;
   DBuf<int64_t> item_t0, ifirst;
   DBuf<double> B, BH, MS, AL, BE, pre_f, end_f, pre_b, end_b, slog32;
+  // Viterbi lane passes
+  DBuf<double> vpre, vend, vgain, vtierows, vpiecemin, qtabs;
+  DBuf<int> vbad, vntie, vties, wk_g, wk_e;
 };
 
 struct tehmm_batch {
@@ -368,7 +376,17 @@ int tehmm_model_create(int N, int K, int S, const double *lt, const double *pi,
   std::vector<double> hltT((size_t)NP * NP, -INFINITY);
   for (int i = 0; i < NP; ++i)
     for (int j = 0; j < NP; ++j) hltT[(size_t)j * NP + i] = hlt[(size_t)i * NP + j];
+  auto group_major = [&](const std::vector<double> &src) {      // [f][o] -> [o / 4][f][o % 4]
+    std::vector<double> g((size_t)NP * NP);
+    for (int f = 0; f < NP; ++f)
+      for (int o = 0; o < NP; ++o) g[(size_t)TEHMM_TG(f, o, NP)] = src[(size_t)f * NP + o];
+    return g;
+  };
+  const std::vector<double> hltG = group_major(hlt), hAG = group_major(hA), hATG = group_major(hAT);
   hipError_t e = m->lt.upload(hlt.data(), hlt.size());
+  if (e == hipSuccess) e = m->ltG.upload(hltG.data(), hltG.size());
+  if (e == hipSuccess) e = m->AG.upload(hAG.data(), hAG.size());
+  if (e == hipSuccess) e = m->ATG.upload(hATG.data(), hATG.size());
   if (e == hipSuccess) e = m->ltT.upload(hltT.data(), hltT.size());
   if (e == hipSuccess) e = m->ltab.upload(hltab.data(), hltab.size());
   if (e == hipSuccess) e = m->A.upload(hA.data(), hA.size());
@@ -665,6 +683,7 @@ static int spec_prepare(tehmm_batch *b, const tehmm_model *m, int CS) {
   HIPCHK(sw.ntie.alloc(nc));
   HIPCHK(sw.ties.alloc(nc * TEHMM_SPEC_MAXT));
   HIPCHK(sw.tierows.alloc(nc * TEHMM_SPEC_MAXT * (size_t)m->NP));
+  HIPCHK(sw.segmin.alloc(nc * (TEHMM_SPEC_MAXT + 1)));
   return TEHMM_OK;
 }
 
@@ -711,14 +730,21 @@ static void launch_vit_spec(tehmm_batch *b, const tehmm_model *m, const Interval
 
 template <int NT>
 static void launch_vit_fix(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em,
-                           const VitChunks &vc, hipStream_t st) {
+                           const VitChunks &vc, bool segmin, hipStream_t st) {
   size_t lds = ((size_t)3 * 64 * (NT + 1) + 2 * 65 * (NT + 2) + (size_t)m->lds_rows * NT + 8) * sizeof(double);
-  allow_lds(k_vit_fix<NT>, lds);
-  hipLaunchKernelGGL((k_vit_fix<NT>), dim3(b->n), dim3(256), lds, st, iv, em, vc, m->N, m->lt.p, m->ltT.p,
-                     m->pi.p, b->tb.p, b->last_state.p, b->vit_lp.p, b->sw.stats.p);
+  allow_lds(k_vit_fix<NT, false>, lds);
+  allow_lds(k_vit_fix<NT, true>, lds);
+  if (segmin)
+    hipLaunchKernelGGL((k_vit_fix<NT, true>), dim3(b->n), dim3(256), lds, st, iv, em, vc, m->N, m->lt.p,
+                       m->ltT.p, m->pi.p, b->tb.p, b->last_state.p, b->vit_lp.p, b->sw.stats.p);
+  else
+    hipLaunchKernelGGL((k_vit_fix<NT, false>), dim3(b->n), dim3(256), lds, st, iv, em, vc, m->N, m->lt.p,
+                       m->ltT.p, m->pi.p, b->tb.p, b->last_state.p, b->vit_lp.p, b->sw.stats.p);
 }
 
 // ---- lane = item passes -----------------------------------------------------------------------
+static LaneGeom lane_geom(const LaneWork &lw);
+
 static int lane_sub_size(int CS) {
   const char *s = std::getenv("TEHMM_LANE_SUB");       // 0 disables; tests use small items
   int L = s ? std::atoi(s) : 512;
@@ -728,7 +754,7 @@ static int lane_sub_size(int CS) {
   return L;
 }
 
-static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, bool want_fb) {
+static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, bool want_fb, bool want_vit) {
   LaneWork &lw = b->lw;
   if (lw.L != L || lw.CS != CS || lw.NP != m->NP || !lw.item_iv.p) {
     std::vector<int> h_iv;
@@ -742,13 +768,15 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
     }
     h_first[b->n] = (int64_t)h_iv.size();
     for (DBuf<double> *d : {&lw.B, &lw.BH, &lw.MS, &lw.AL, &lw.BE, &lw.pre_f, &lw.end_f, &lw.pre_b, &lw.end_b,
-                            &lw.slog32})
+                            &lw.slog32, &lw.vpre, &lw.vend, &lw.vgain, &lw.vtierows, &lw.vpiecemin})
       d->release();
-    lw.ok_f.release();
-    lw.ok_b.release();
+    for (DBuf<int> *d : {&lw.ok_f, &lw.ok_b, &lw.vbad, &lw.vntie, &lw.vties}) d->release();
     lw.L = L; lw.CS = CS; lw.NP = m->NP;
     lw.n_items = (int)h_iv.size();
     lw.n_groups = (lw.n_items + 63) / 64;
+    lw.h_iv = h_iv;
+    lw.h_t0 = h_t0;
+    lw.h_first = h_first;
     HIPCHK(lw.item_iv.upload(h_iv.data(), h_iv.size()));
     HIPCHK(lw.item_t0.upload(h_t0.data(), h_t0.size()));
     HIPCHK(lw.ifirst.upload(h_first.data(), h_first.size()));
@@ -756,8 +784,6 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
   const size_t rows = (size_t)std::max(1, lw.n_groups) * L * 64;        // item-interleaved positions
   const size_t vecs = (size_t)std::max(1, lw.n_groups) * 64 * m->NP;
   if (want_fb && !lw.AL.p) {
-    HIPCHK(lw.BH.alloc(rows * m->NP));
-    HIPCHK(lw.MS.alloc(rows));
     HIPCHK(lw.AL.alloc(rows * m->NP));
     HIPCHK(lw.BE.alloc(rows * m->NP));
     HIPCHK(lw.pre_f.alloc(vecs));
@@ -768,7 +794,80 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
     HIPCHK(lw.ok_f.alloc((size_t)std::max(1, b->sw.n_chunks)));
     HIPCHK(lw.ok_b.alloc((size_t)std::max(1, b->sw.n_chunks)));
   }
+  if (want_fb && !lw.BH.p) {
+    HIPCHK(lw.BH.alloc(rows * m->NP));
+    if (!lw.MS.p) HIPCHK(lw.MS.alloc(rows));
+  }
+  if (want_vit && !lw.B.p) {
+    const size_t ni = (size_t)std::max(1, lw.n_groups) * 64;
+    HIPCHK(lw.B.alloc(rows * m->NP));
+    if (!lw.MS.p) HIPCHK(lw.MS.alloc(rows));
+    HIPCHK(lw.vpre.alloc(vecs));
+    HIPCHK(lw.vend.alloc(vecs));
+    HIPCHK(lw.vgain.alloc(ni));
+    HIPCHK(lw.vbad.alloc(ni));
+    HIPCHK(lw.vntie.alloc(ni));
+    HIPCHK(lw.vties.alloc(ni * TEHMM_LANE_MAXTI));
+    HIPCHK(lw.vtierows.alloc(ni * TEHMM_LANE_MAXTI * m->NP));
+    HIPCHK(lw.vpiecemin.alloc(ni * (TEHMM_LANE_MAXTI + 1)));
+    HIPCHK(hipMemset(lw.vbad.p, 0, ni * sizeof(int)));
+    HIPCHK(hipMemset(lw.vntie.p, 0, ni * sizeof(int)));
+  }
   return TEHMM_OK;
+}
+
+static VitItems lane_vit_items(LaneWork &lw) {
+  VitItems vi;
+  vi.pre = lw.vpre.p; vi.end = lw.vend.p; vi.gain = lw.vgain.p; vi.bad = lw.vbad.p; vi.ntie = lw.vntie.p;
+  vi.ties = lw.vties.p; vi.tierows = lw.vtierows.p; vi.piecemin = lw.vpiecemin.p;
+  return vi;
+}
+
+// quantised transition table of binade e as the P2 lane pass wants it (tehmm_spec.hip.h:96-107):
+// 64 * R_u(lt[f][j]) + (63 - f) * u, pads -inf.  false if an entry sits exactly between two grid points.
+static bool quantised_table(const tehmm_model *m, int e, double *out) {
+  const int N = m->N, NP = m->NP;
+  const double u = std::ldexp(1.0, e - 52), M = std::ldexp(1.5, e), half_u = 0.5 * u;
+  bool ok = true;
+  for (int f = 0; f < NP; ++f)
+    for (int j = 0; j < NP; ++j) {
+      double v = -INFINITY;
+      if (f < N && j < N) {
+        const double z = m->h_lt[(size_t)f * N + j];
+        volatile double zm = z + M;
+        const double q = zm - M;
+        if (std::fabs(z - q) == half_u) ok = false;
+        v = 64.0 * q + (double)(63 - f) * u;
+      }
+      out[(size_t)TEHMM_TG(f, j, NP)] = v;
+    }
+  return ok;
+}
+
+template <int NT>
+static void launch_vit_lane(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const VitChunks &vc,
+                            bool quant, int Wu, int n_work, int e0, hipStream_t st) {
+  LaneWork &lw = b->lw;
+  const LaneGeom lg = lane_geom(lw);
+  const VitItems vi = lane_vit_items(lw);
+  if (n_work <= 0) return;
+  const dim3 grid((n_work + 3) / 4);
+  if (quant)
+    hipLaunchKernelGGL((k_vit_lane<NT, true>), grid, dim3(256), 0, st, iv, lg, vc, vi, m->N, Wu,
+                       (const int *)lw.wk_g.p, (const int *)lw.wk_e.p, n_work, (const double *)lw.qtabs.p, e0,
+                       (const double *)lw.B.p, b->tb.p);
+  else
+    hipLaunchKernelGGL((k_vit_lane<NT, false>), grid, dim3(256), 0, st, iv, lg, vc, vi, m->N, Wu,
+                       (const int *)nullptr, (const int *)nullptr, n_work, (const double *)m->ltG.p, 0,
+                       (const double *)lw.B.p, b->tb.p);
+}
+
+template <int NT>
+static void launch_vit_stitch(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const VitChunks &vc,
+                              hipStream_t st) {
+  LaneWork &lw = b->lw;
+  hipLaunchKernelGGL((k_vit_stitch<NT>), dim3((vc.n + 3) / 4), dim3(256), 0, st, iv, lane_geom(lw), vc,
+                     lane_vit_items(lw), m->N);
 }
 
 static LaneGeom lane_geom(const LaneWork &lw) {
@@ -792,9 +891,9 @@ static void launch_fb_lane(tehmm_batch *b, const tehmm_model *m, const IntervalT
   LaneWork &lw = b->lw;
   const LaneGeom lg = lane_geom(lw);
   const dim3 grid((lw.n_groups + 3) / 4);
-  hipLaunchKernelGGL((k_fb_lane<NT, 0>), grid, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->A.p, lw.BH.p,
+  hipLaunchKernelGGL((k_fb_lane<NT, 0>), grid, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->AG.p, lw.BH.p,
                      lw.MS.p, lw.AL.p, lw.pre_f.p, lw.end_f.p, lw.slog32.p);
-  hipLaunchKernelGGL((k_fb_lane<NT, 1>), grid, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->AT.p, lw.BH.p,
+  hipLaunchKernelGGL((k_fb_lane<NT, 1>), grid, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->ATG.p, lw.BH.p,
                      lw.MS.p, lw.BE.p, lw.pre_b.p, lw.end_b.p, (double *)nullptr);
   hipLaunchKernelGGL((k_fb_stitch<NT>), dim3((fc.n + 3) / 4), dim3(256), 0, st, iv, lg, fc, m->N, lw.pre_f.p,
                      lw.end_f.p, lw.slog32.p, lw.pre_b.p, lw.end_b.p, lw.ok_f.p, lw.ok_b.p);
@@ -889,45 +988,64 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     if (rc) return rc;
   }
   SpecWork &sw = b->sw;
+  LaneWork &lw = b->lw;
   const EmisTab emg = without_lds_tables(em);
-  const int eV = 0, eP = 4;
-  bool flane = false;
+  const int eV = 0, eP = 5;
+  const int LS = (vspec || fspec) ? lane_sub_size(CS) : 0;
+  const bool vlane = vspec && LS > 0, flane = fspec && LS > 0;
+  const char *wus = std::getenv("TEHMM_LANE_WARMUP");
+  const int WuF = std::min(LS, std::max(1, wus ? std::atoi(wus) : 96));       // forward / backward warm-up
+  const int WuV = std::min(LS, 64);                                            // Viterbi warm-up (multiple of 32)
   VitChunks vc;
   std::vector<double> gain;
   if (vit) (void)hipEventRecord(b->ev[eV], b->sV);
+  if (postr) (void)hipEventRecord(b->ev[eP], b->sP);
+  if (vlane || flane) {
+    // emission rows of every position, once, item-interleaved (log rows for Viterbi, linear for fwd/bwd)
+    rc = lane_prepare(b, m, CS, LS, flane, vlane);
+    if (rc) return rc;
+    hipStream_t st = vlane ? b->sV : b->sP;
+#define CALL(NT_) launch_emis_lane<NT_>(b, m, iv, emg, vlane, flane, st)
+    TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+    if (vlane) (void)hipEventRecord(b->ev[eV + 4], st);
+    if (flane) {
+      (void)hipEventRecord(b->evX[0], st);
+      if (vlane) (void)hipStreamWaitEvent(b->sP, b->evX[0], 0);
+      (void)hipEventRecord(b->ev[eP + 4], b->sP);
+    }
+  }
   if (vspec) {
     // chunk-parallel exact Viterbi: P0 (plain gains) -> binades -> P2 (quantised) -> fix-up chain
     hipStream_t st = b->sV;
     vc.iv = sw.iv.p; vc.t0 = sw.t0.p; vc.first = sw.first.p; vc.n = sw.n_chunks; vc.CS = CS;
     vc.e = sw.e.p; vc.gain = sw.gain.p; vc.ok = sw.ok.p; vc.wmin = sw.wmin.p; vc.rows = sw.rows.p;
-    vc.ntie = sw.ntie.p; vc.ties = sw.ties.p; vc.tierows = sw.tierows.p;
-#define CALL(NT_) launch_vit_spec<NT_>(b, m, iv, emg, vc, false, st)
-    TEHMM_NT_DISPATCH(m->NP, CALL)
+    vc.ntie = sw.ntie.p; vc.ties = sw.ties.p; vc.tierows = sw.tierows.p; vc.segmin = sw.segmin.p;
+    if (vlane) {
+#define CALL(NT_) launch_vit_lane<NT_>(b, m, iv, vc, false, WuV, lw.n_groups, 0, st)
+      TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
-    gain.resize((size_t)std::max(1, sw.n_chunks));
-    HIPCHK(hipMemcpyAsync(gain.data(), sw.gain.p, gain.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      gain.resize((size_t)std::max(1, lw.n_groups) * 64);
+      HIPCHK(hipMemcpyAsync(gain.data(), lw.vgain.p, gain.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    } else {
+#define CALL(NT_) launch_vit_spec<NT_>(b, m, iv, emg, vc, false, st)
+      TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+      gain.resize((size_t)std::max(1, sw.n_chunks));
+      HIPCHK(hipMemcpyAsync(gain.data(), sw.gain.p, gain.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
   }
   if (postr) {
     hipStream_t st = b->sP;
-    (void)hipEventRecord(b->ev[eP], st);
-    const int LS = fspec ? lane_sub_size(CS) : 0;
-    if (fspec && LS > 0) {
-      // lane = item passes (emission rows, forward, backward, links), then the two sequential chains
-      // on the item-interleaved rows, then the transposing combine
-      rc = lane_prepare(b, m, CS, LS, true);
-      if (rc) return rc;
+    if (flane) {
+      // lane = item passes (forward, backward, links), then the two sequential chains on the
+      // item-interleaved rows, then the transposing combine
       FbChunks fc;
       fc.iv = sw.iv.p; fc.t0 = sw.t0.p; fc.first = sw.first.p; fc.n = sw.n_chunks; fc.CS = CS;
       fc.scale = sw.scale.p; fc.wstart = sw.wstart.p;
-      const char *wus = std::getenv("TEHMM_LANE_WARMUP");
-      const int Wu = std::min(LS, std::max(1, wus ? std::atoi(wus) : 96));
       (void)hipMemsetAsync(b->dead.p, 0, (size_t)(b->n + 1) * sizeof(int), st);
       (void)hipMemsetAsync(sw.stats.p + 2, 0, 4 * sizeof(int), st);
-#define CALL(NT_) launch_emis_lane<NT_>(b, m, iv, emg, false, true, st)
-      TEHMM_NT_DISPATCH(m->NP, CALL)
-#undef CALL
-      (void)hipEventRecord(b->ev[eP + 4], st);
-#define CALL(NT_) launch_fb_lane<NT_>(b, m, iv, fc, Wu, st)
+#define CALL(NT_) launch_fb_lane<NT_>(b, m, iv, fc, WuF, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
       (void)hipEventRecord(b->ev[eP + 3], st);
@@ -943,7 +1061,6 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
 #undef CALL
       hipLaunchKernelGGL(k_poison_dead, dim3(64, std::min(b->n, 1024)), dim3(256), 0, st, iv, b->dead.p, m->N,
                          b->post.p, b->fwd_lp.p);
-      flane = true;
     } else if (fspec) {
       // chunk-parallel forward / backward: speculative rows from uniform starts, then the two
       // sequential chains (forward on this stream, backward on its own) with verified jumps
@@ -987,7 +1104,86 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   }
   if (vit) {
     hipStream_t st = b->sV;
-    if (vspec) {
+    if (vlane) {
+      HIPCHK(hipStreamSynchronize(st));
+      // item gains -> chunk gains -> binades; one P2 wave per (group, binade) pair
+      std::vector<double> cgain((size_t)std::max(1, sw.n_chunks), 0.0);
+      const int SUB = CS / LS;
+      for (int c = 0; c < sw.n_chunks; ++c) {
+        const int id = sw.h_iv[(size_t)c];
+        const int64_t it0 = lw.h_first_item(id) + sw.h_t0[(size_t)c] / LS;
+        double gsum = 0.0;
+        const bool full = sw.h_t0[(size_t)c] + CS <= b->h_len[id];
+        if (!full || c == sw.h_first[id]) gsum = std::nan("");
+        else for (int k = 0; k < SUB; ++k) gsum += gain[(size_t)(it0 + k)];
+        cgain[(size_t)c] = gsum;
+      }
+      // chunks the lanes did not run carry NaN; the prefix sums of spec_assign_binades still need a
+      // number for them: use the mean gain per position of the interval's speculated chunks
+      for (int i = 0; i < b->n; ++i) {
+        double sum = 0.0;
+        int cnt = 0;
+        for (int64_t c = sw.h_first[i]; c < sw.h_first[i + 1]; ++c)
+          if (cgain[(size_t)c] == cgain[(size_t)c]) { sum += cgain[(size_t)c]; ++cnt; }
+        const double mean = cnt ? sum / cnt : std::nan("");
+        for (int64_t c = sw.h_first[i]; c < sw.h_first[i + 1]; ++c)
+          if (!(cgain[(size_t)c] == cgain[(size_t)c])) {
+            const int64_t clen = std::min<int64_t>(CS, b->h_len[i] - sw.h_t0[(size_t)c]);
+            cgain[(size_t)c] = (c == sw.h_first[i] || clen < CS) ? mean * (double)clen / (double)CS : std::nan("");
+          }
+      }
+      std::vector<int> he;
+      spec_assign_binades(b, cgain, he);
+      // quantised tables of the binades in use
+      int emin = INT_MAX, emax = INT_MIN;
+      for (int c = 0; c < sw.n_chunks; ++c)
+        if (he[(size_t)c] != TEHMM_SPEC_NONE) { emin = std::min(emin, he[(size_t)c]); emax = std::max(emax, he[(size_t)c]); }
+      std::vector<int> wk_g, wk_e;
+      if (emin <= emax) {
+        const size_t tsz = (size_t)m->NP * m->NP;
+        std::vector<double> qt((size_t)(emax - emin + 1) * tsz);
+        std::vector<char> eok((size_t)(emax - emin + 1), 1);
+        for (int e = emin; e <= emax; ++e) eok[(size_t)(e - emin)] = quantised_table(m, e, qt.data() + (size_t)(e - emin) * tsz);
+        for (int c = 0; c < sw.n_chunks; ++c)
+          if (he[(size_t)c] != TEHMM_SPEC_NONE && !eok[(size_t)(he[(size_t)c] - emin)]) he[(size_t)c] = TEHMM_SPEC_NONE;
+        HIPCHK(lw.qtabs.upload(qt.data(), qt.size()));
+        for (int g = 0; g < lw.n_groups; ++g) {
+          int seen[8];
+          int ns = 0;
+          for (int ln = 0; ln < 64 && g * 64 + ln < lw.n_items; ++ln) {
+            const size_t item = (size_t)g * 64 + ln;
+            const int id = lw.h_iv[item];
+            const int e = he[(size_t)(sw.h_first[id] + lw.h_t0[item] / CS)];
+            if (e == TEHMM_SPEC_NONE) continue;
+            bool dup = false;
+            for (int q = 0; q < ns; ++q) dup = dup || seen[q] == e;
+            if (!dup && ns < 8) { seen[ns++] = e; wk_g.push_back(g); wk_e.push_back(e); }
+            else if (!dup) he[(size_t)(sw.h_first[id] + lw.h_t0[item] / CS)] = TEHMM_SPEC_NONE;
+          }
+        }
+      }
+      const int n_work = (int)wk_g.size();
+      if (n_work > 0) {
+        HIPCHK(lw.wk_g.upload(wk_g.data(), wk_g.size()));
+        HIPCHK(lw.wk_e.upload(wk_e.data(), wk_e.size()));
+      }
+      HIPCHK(hipMemcpyAsync(sw.e.p, he.data(), he.size() * sizeof(int), hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(sw.gain.p, cgain.data(), cgain.size() * sizeof(double), hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemsetAsync(sw.ok.p, 0, he.size() * sizeof(int), st));
+      HIPCHK(hipMemsetAsync(sw.stats.p, 0, 2 * sizeof(int), st));
+      HIPCHK(hipMemsetAsync(lw.vbad.p, 0, (size_t)std::max(1, lw.n_groups) * 64 * sizeof(int), st));
+      HIPCHK(hipMemsetAsync(lw.vntie.p, 0, (size_t)std::max(1, lw.n_groups) * 64 * sizeof(int), st));
+#define CALL(NT_) launch_vit_lane<NT_>(b, m, iv, vc, true, WuV, n_work, emin, st)
+      TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+#define CALL(NT_) launch_vit_stitch<NT_>(b, m, iv, vc, st)
+      TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+      (void)hipEventRecord(b->ev[eV + 3], st);
+#define CALL(NT_) launch_vit_fix<NT_>(b, m, iv, em, vc, true, st)
+      TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+    } else if (vspec) {
       HIPCHK(hipStreamSynchronize(st));
       std::vector<int> he;
       spec_assign_binades(b, gain, he);
@@ -998,7 +1194,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
       (void)hipEventRecord(b->ev[eV + 3], st);
-#define CALL(NT_) launch_vit_fix<NT_>(b, m, iv, em, vc, st)
+#define CALL(NT_) launch_vit_fix<NT_>(b, m, iv, em, vc, false, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
     } else if (coop) {
@@ -1018,7 +1214,14 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
                          b->n_chunks, b->d_chunk_iv.p, b->d_chunk0.p, b->TBW, b->tb.p, b->bstate.p,
                          b->paths.p);
     (void)hipEventRecord(b->ev[eV + 2], st);
-    if (vspec) {
+    if (vlane) {
+      b->tnames.push_back("emission_rows");
+      b->tpairs.push_back({eV, eV + 4});
+      b->tnames.push_back("viterbi_speculate");
+      b->tpairs.push_back({eV + 4, eV + 3});
+      b->tnames.push_back("viterbi");
+      b->tpairs.push_back({eV + 3, eV + 1});
+    } else if (vspec) {
       b->tnames.push_back("viterbi_speculate");
       b->tpairs.push_back({eV, eV + 3});
       b->tnames.push_back("viterbi");
@@ -1032,8 +1235,10 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   }
   if (postr) {
     if (flane) {
-      b->tnames.push_back("emission_rows");
-      b->tpairs.push_back({eP, eP + 4});
+      if (!vlane) {
+        b->tnames.push_back("emission_rows");
+        b->tpairs.push_back({eP, eP + 4});
+      }
       b->tnames.push_back("forward_backward_speculate");
       b->tpairs.push_back({eP + 4, eP + 3});
       b->tnames.push_back("forward_backward");

@@ -24,6 +24,11 @@ namespace tehmm {
 
 // constant address space: uniform loads from it become scalar loads (s_load), their results SGPR operands
 typedef __attribute__((address_space(4))) const double const_f64;
+// Tables read as scalar operands are stored output-group-major: G[o / 4][f][o % 4] (NT * 4 contiguous
+// doubles per group of four outputs).  A step then finishes four outputs at a time -- four independent
+// accumulator chains fed by one contiguous scalar stream -- so only the state vector, its successor
+// and a handful of temporaries are ever live (v[NT] + out[NT] doubles = 4 * NT VGPRs).
+#define TEHMM_TG(f, o, NT) ((((o) >> 2) * (NT) + (f)) * 4 + ((o) & 3))
 
 
 
@@ -108,18 +113,29 @@ void k_fb_lane(IntervalTab iv, LaneGeom lg, int N, int CS, int Wu, const double 
   double slog = 0.0;
 
   // out[o] = sum_f v[f] * tab[f][o]
-  // (the table pointer is laundered every step: hoisting 1296 loop-invariant scalar loads out of the
+  // (the table offset is laundered every step: hoisting 1296 loop-invariant scalar loads out of the
+  // position loop would spill thousands of SGPRs; re-issued s_loads hit the scalar cache)
+  // out[o] = sum_f v[f] * tab[f][o]
+  // (the table offset is laundered every step: hoisting 1296 loop-invariant scalar loads out of the
   // position loop would spill thousands of SGPRs; re-issued s_loads hit the scalar cache)
   auto matvec = [&](double (&acc)[NT]) {
     int z = 0;
     asm volatile("" : "+s"(z));
     const_f64 *tp = (const_f64 *)(size_t)tab + z;
 #pragma unroll
-    for (int o = 0; o < NT; ++o) acc[o] = 0.0;
+    for (int og = 0; og < NT / 4; ++og) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-    for (int f = 0; f < NT; ++f) {
-#pragma unroll
-      for (int o = 0; o < NT; ++o) acc[o] = fma(v[f], tp[f * NT + o], acc[o]);
+      for (int f = 0; f < NT; ++f) {
+        a0 = fma(v[f], tp[(og * NT + f) * 4 + 0], a0);
+        a1 = fma(v[f], tp[(og * NT + f) * 4 + 1], a1);
+        a2 = fma(v[f], tp[(og * NT + f) * 4 + 2], a2);
+        a3 = fma(v[f], tp[(og * NT + f) * 4 + 3], a3);
+      }
+      acc[4 * og] = a0;
+      acc[4 * og + 1] = a1;
+      acc[4 * og + 2] = a2;
+      acc[4 * og + 3] = a3;
     }
   };
   auto expo = [&](const double (&a)[NT]) {
@@ -328,6 +344,291 @@ __global__ __launch_bounds__(256) void k_combine_lane(IntervalTab iv, LaneGeom l
       }
     }
     __syncthreads();
+  }
+}
+
+
+// ==========================================================================================
+// Viterbi lane passes.  Same arithmetic as k_vit_spec (tehmm_spec.hip.h: plain fp64 for P0, the
+// binade's exact integer max-plus recurrence for P2), one item per lane.  P2 needs the quantised
+// transition table of the item's binade as scalar operands, so a wave is launched per (group,
+// binade) pair and lanes of another binade sit idle (binades change ~8 times per interval).
+//   P0 (QUANT = false): gain[item] = max W_end - max W_pre  (score gained over the official range by
+//       the converged vector: the host's prefix sums place every chunk in its binade);
+//   P2 (QUANT = true) : packed traceback bytes straight into tb[(pos0 + t) * NT + state], W rows at
+//       every 32nd position straight into vc.rows (lane frame), pre / end vectors, ties, per-piece
+//       minima.  k_vit_stitch then links the items of a chunk into segments for k_vit_fix.
+// ==========================================================================================
+#define TEHMM_LANE_MAXTI 8
+struct VitItems {
+  double *pre, *end;        // [group][NT][64]  lane-frame vectors of positions t0-1 and t0+L-1
+  double *gain;             // P0: [item]
+  int *bad;                 // P2: [item] the item cannot be used (dead vector, impossible row, > MAXTI ties)
+  int *ntie;                // P2: [item] ties inside the official range
+  int *ties;                // P2: [item][MAXTI] tie positions relative to t0, ascending
+  double *tierows;          // P2: [item][MAXTI][NT] lane-frame row of the position before each tie
+  double *piecemin;         // P2: [item][MAXTI + 1] lowest live value of each piece between ties
+};
+
+template <int NT, bool QUANT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_vit_lane(IntervalTab iv, LaneGeom lg, VitChunks vc, VitItems vi, int N, int Wu, const int *wk_g,
+                const int *wk_e, int n_work, const double *__restrict__ tabs, int e0,
+                const double *__restrict__ B, uint8_t *tb) {
+  const int lane = threadIdx.x & 63;
+  const int wk = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wave-uniform
+  if (wk >= n_work) return;
+  const int g = QUANT ? wk_g[wk] : wk;
+  const int e = QUANT ? wk_e[wk] : 0;
+  const int L = lg.L, CS = vc.CS;
+  const int64_t item = (int64_t)g * 64 + lane;
+  const bool valid = item < lg.n_items;
+  const int id = valid ? lg.item_iv[item] : 0;
+  const int64_t t0 = valid ? lg.item_t0[item] : 0;
+  const int64_t T = iv.len[id], p0 = iv.pos0[id];
+  const int64_t ct0 = (t0 / CS) * CS;
+  const int64_t c = vc.first[id] + t0 / CS;
+  bool run = valid && ct0 > 0 && ct0 + CS <= T;      // first chunk and ragged tail: exact chain only
+  if (QUANT) run = run && vc.e[c] == e;
+  if (!__any(run)) return;
+  const int64_t nb = run ? item - 1 : item;
+  const_f64 *tab0 = (const_f64 *)(size_t)tabs + (QUANT ? (int64_t)(e - e0) * NT * NT : 0);
+  const double u = QUANT ? ldexp(1.0, e - 52) : 0.0;
+  const double M = QUANT ? ldexp(1.5, e) : 0.0;          // fl(z + M) - M rounds z to the grid u
+  const double half_u = 0.5 * u;
+  const double inv_u = QUANT ? ldexp(1.0, 52 - e) : 0.0;
+  double W[NT];                                          // QUANT: 64 x (value - base); plain: value
+#pragma unroll
+  for (int j = 0; j < NT; ++j) W[j] = j < N ? 0.0 : -INFINITY;
+  double base = 0.0, pmin = INFINITY;
+  int nt = 0;
+  bool bad = false;
+  uint32_t *tb32 = (uint32_t *)tb;
+
+  auto restart = [&]() {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) W[j] = j < N ? 0.0 : -INFINITY;
+    base = 0.0;
+    pmin = INFINITY;
+  };
+  // one position: s = position relative to t0 (negative: warm-up), bp = its emission row.  The row is
+  // read twice (tie scan, then update) so that it never has to sit in registers next to W and x.
+  auto step = [&](const double *bp, int s) {
+    const bool official = s >= 0;
+    bool tie = false;
+    if (QUANT) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const double bj = bp[(int64_t)j << 6];
+        const double q = (bj + M) - M;
+        if (j == 0) bad = bad || bj != bj;
+        if ((j < NT - 8 || j < N) && fabs(bj - q) == half_u) tie = true;
+      }
+      if (__any(tie && run)) {
+        // a rounding tie at this position: close the piece (record W_{t-1}); the vector restarts from
+        // zeros behind it and the exact chain handles the position itself
+        if (tie && run && official) {
+          if (nt < TEHMM_LANE_MAXTI) {
+            vi.ties[item * TEHMM_LANE_MAXTI + nt] = s;
+            double *tr = vi.tierows + (item * TEHMM_LANE_MAXTI + nt) * NT;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) tr[j] = W[j] * 0.015625 + base;
+            vi.piecemin[item * (TEHMM_LANE_MAXTI + 1) + nt] = pmin;
+          }
+          ++nt;
+        }
+      }
+    }
+    // Wn[o] = max_f W[f] + tab[f][o]  (+ emission), four outputs at a time (tab scalar; QUANT: it carries
+    // the from-index in its low bits)
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    const_f64 *tp = tab0 + z;
+    double Wn[NT];
+    uint32_t pk[NT / 4];
+#pragma unroll
+    for (int og = 0; og < NT / 4; ++og) {
+      double x0 = W[0] + tp[(og * NT) * 4 + 0], x1 = W[0] + tp[(og * NT) * 4 + 1];
+      double x2 = W[0] + tp[(og * NT) * 4 + 2], x3 = W[0] + tp[(og * NT) * 4 + 3];
+#pragma unroll
+      for (int f = 1; f < NT; ++f) {
+        x0 = fmax(x0, W[f] + tp[(og * NT + f) * 4 + 0]);
+        x1 = fmax(x1, W[f] + tp[(og * NT + f) * 4 + 1]);
+        x2 = fmax(x2, W[f] + tp[(og * NT + f) * 4 + 2]);
+        x3 = fmax(x3, W[f] + tp[(og * NT + f) * 4 + 3]);
+      }
+      const double xs[4] = {x0, x1, x2, x3};
+      uint32_t pw = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int o = 4 * og + q;
+        const double bo = bp[(int64_t)o << 6];
+        if (QUANT) {
+          // xs = 64 * (best value) + (63 - first arg-max) * u  (exact)
+          const double bq = 64.0 * ((bo + M) - M);
+          const double m = xs[q];
+          const double k = m * inv_u;                          // m / u, an integer
+          const double r = k - 64.0 * floor(k * 0.015625);     // k mod 64 in [0, 63]
+          const int arg = 63 - (int)r;
+          // a dead state (m = -inf) makes r NaN: maxNum(NaN, -inf) puts -inf back without a branch
+          Wn[o] = fmax((m - r * u) + bq, -INFINITY);
+          pw |= (uint32_t)(arg & 63) << (8 * q);
+        } else {
+          if (o == 0) bad = bad || bo != bo;
+          Wn[o] = xs[q] + bo;
+        }
+      }
+      pk[og] = pw;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) W[j] = Wn[j];
+    if (QUANT) {
+      if (run && official && !tie) {
+        uint32_t *dst = tb32 + (p0 + t0 + s) * (NT / 4);
+#pragma unroll
+        for (int d = 0; d < NT / 4; ++d) dst[d] = pk[d];
+      }
+      if (__any(tie)) {
+        if (tie) restart();
+      }
+      double wl = INFINITY;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wl = fmin(wl, (j < NT - 8 || j < N) ? W[j] : INFINITY);
+      if (!tie) pmin = fmin(pmin, wl * 0.015625 + base);
+    }
+  };
+  // re-base so that the index bits keep fitting; QUANT records the row of an official position
+  auto rebase = [&](int s) {
+    if (!QUANT) return;
+    double mx = W[0];
+#pragma unroll
+    for (int j = 1; j < NT; ++j) mx = fmax(mx, W[j]);
+    if (mx > -INFINITY) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) W[j] -= mx;
+      base += mx * 0.015625;
+    } else {
+      bad = true;
+    }
+    if (s >= 0 && run) {
+      double *row = vc.rows + ((int64_t)c * (CS / 32) + (t0 - ct0 + s) / 32) * NT;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) row[j] = W[j] * 0.015625 + base;
+    }
+  };
+  auto vec_out = [&](double *dst) {
+    const int64_t po = (((int64_t)g * NT) << 6) + lane;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) dst[po + ((int64_t)j << 6)] = QUANT ? W[j] * 0.015625 + base : W[j];
+  };
+  auto vec_max = [&]() {
+    double mx = W[0];
+#pragma unroll
+    for (int j = 1; j < NT; ++j) mx = fmax(mx, W[j]);
+    return mx;
+  };
+
+  double g0 = 0.0;
+  for (int s = -Wu; s < L; ++s) {                       // one loop: the unrolled step exists once
+    if (s == 0) {
+      if (run) vec_out(vi.pre);
+      pmin = INFINITY;
+      if (!QUANT) g0 = vec_max();
+    }
+    step(B + (s < 0 ? lane_row(lg, NT, nb, L + s) : lane_row(lg, NT, item, s)), s);
+    if (((s + Wu) & 31) == 31) rebase(s);
+  }
+  if (run) {
+    vec_out(vi.end);
+    if (QUANT) {
+      vi.ntie[item] = nt;
+      vi.bad[item] = (bad || nt > TEHMM_LANE_MAXTI) ? 1 : 0;
+      vi.piecemin[item * (TEHMM_LANE_MAXTI + 1) + min(nt, TEHMM_LANE_MAXTI)] = pmin;
+    } else {
+      const double g1 = vec_max();
+      vi.gain[item] = bad ? __longlong_as_double(0x7ff8000000000000LL) : g1 - g0;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Links of the Viterbi lane pass, one wave per chunk (lane = state): items whose pre vector equals
+// the previous item's end vector up to ONE constant (exactly) continue its segment -- their rows,
+// tie rows and minima are shifted into the segment's frame; a failed link, like a rounding tie,
+// starts a new segment (recorded as a tie at the item's first position).  Output: the chunk's
+// segment list in the form k_vit_fix expects (ties, tierows, rows, segmin, ok).
+// ------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k_vit_stitch(IntervalTab iv, LaneGeom lg, VitChunks vc, VitItems vi,
+                                                    int N) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= vc.n) return;
+  if (vc.e[c] == TEHMM_SPEC_NONE) {
+    if (lane == 0) { vc.ok[c] = 0; vc.ntie[c] = 0; }
+    return;
+  }
+  const int id = vc.iv[c];
+  const int64_t ct0 = vc.t0[c];
+  const int L = lg.L, SUB = vc.CS / L, R = L / 32;
+  const int64_t item0 = lg.ifirst[id] + ct0 / L;
+  const bool live = lane < N;
+  const int jl = min(lane, NT - 1);
+  auto at = [&](const double *p, int64_t item) { return p[((((item >> 6) * NT) + jl) << 6) + (item & 63)]; };
+  double off = 0.0, off_end = 0.0, segmin = INFINITY;
+  int nT = 0;
+  bool okc = true;
+  for (int k = 0; k < SUB; ++k) {
+    const int64_t item = item0 + k;
+    okc = okc && vi.bad[item] == 0;
+    off = off_end;
+    if (k > 0) {
+      const double a = at(vi.pre, item), bp = at(vi.end, item - 1);
+      const bool both_dead = a == -INFINITY && bp == -INFINITY;
+      const double d = bp - a;
+      const double d0 = wave_max_live((both_dead || !live) ? -INFINITY : d, live);
+      const bool same = __all(!live || both_dead || d == d0) && d0 == d0 && d0 > -INFINITY && d0 < INFINITY;
+      if (same) {
+        off = off_end + d0;
+      } else {
+        if (nT < TEHMM_SPEC_MAXT) {
+          if (lane == 0) {
+            vc.ties[(int64_t)c * TEHMM_SPEC_MAXT + nT] = k * L;
+            vc.segmin[(int64_t)c * (TEHMM_SPEC_MAXT + 1) + nT] = segmin;
+          }
+          if (lane < NT) vc.tierows[((int64_t)c * TEHMM_SPEC_MAXT + nT) * NT + lane] = bp + off_end;
+        }
+        ++nT;
+        off = 0.0;
+        segmin = INFINITY;
+      }
+    }
+    const int nti = min(vi.ntie[item], TEHMM_LANE_MAXTI);
+    const int first_tie = nti > 0 ? vi.ties[item * TEHMM_LANE_MAXTI] : L;
+    if (off != 0.0 && lane < NT) {
+      for (int m = 0; m < R && 32 * m + 31 < first_tie; ++m)
+        vc.rows[((int64_t)c * (vc.CS / 32) + k * R + m) * NT + lane] += off;
+    }
+    segmin = fmin(segmin, vi.piecemin[item * (TEHMM_LANE_MAXTI + 1)] + off);
+    for (int i = 0; i < nti; ++i) {
+      if (nT < TEHMM_SPEC_MAXT) {
+        if (lane == 0) {
+          vc.ties[(int64_t)c * TEHMM_SPEC_MAXT + nT] = k * L + vi.ties[item * TEHMM_LANE_MAXTI + i];
+          vc.segmin[(int64_t)c * (TEHMM_SPEC_MAXT + 1) + nT] = segmin;
+        }
+        if (lane < NT)
+          vc.tierows[((int64_t)c * TEHMM_SPEC_MAXT + nT) * NT + lane] =
+              vi.tierows[(item * TEHMM_LANE_MAXTI + i) * NT + lane] + (i == 0 ? off : 0.0);
+      }
+      ++nT;
+      segmin = vi.piecemin[item * (TEHMM_LANE_MAXTI + 1) + i + 1];
+    }
+    off_end = nti > 0 ? 0.0 : off;
+  }
+  if (lane == 0) {
+    vc.segmin[(int64_t)c * (TEHMM_SPEC_MAXT + 1) + min(nT, TEHMM_SPEC_MAXT)] = segmin;
+    vc.ntie[c] = nT;
+    vc.ok[c] = (okc && nT <= TEHMM_SPEC_MAXT) ? 1 : 0;
   }
 }
 

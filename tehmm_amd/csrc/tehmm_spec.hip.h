@@ -51,6 +51,7 @@ struct VitChunks {
   int *ntie;              // P2: number of tie positions in the chunk (> TEHMM_SPEC_MAXT: unusable)
   int *ties;              // P2: [chunk][MAXT] tie positions relative to t0, ascending
   double *tierows;        // P2: [chunk][MAXT][NT] W row of the position just before each tie
+  double *segmin;         // lane passes: [chunk][MAXT + 1] lowest live W of each segment (its frame)
 };
 #define TEHMM_SPEC_MAXT 32
 
@@ -212,7 +213,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //   can prepare exactly that block.
 // LDS (doubles): bring [3][64][RS] | Vring [2][65][VS] | ltab [lds_rows][NT] | seq (4 x i64, gen)
 // ------------------------------------------------------------------------------------------
-template <int NT>
+// SEGMIN: the chunk data come from the lane passes (tehmm_lane.hip.h): "stays in the binade up to the
+// segment end" is decided from the segment's recorded minimum instead of the P0 gain estimate.
+template <int NT, bool SEGMIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_lt,
                const double *g_ltT, const double *g_pi, uint8_t *tb, int *last_state,
@@ -277,14 +280,17 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
         const int64_t g = ct0 + ((cur + 16 - ct0) / 32) * 32 + 31;   // smallest recorded row >= cur + 16
         const int pg = (int)(g - cur);                          // in-block step of the check, 16..47
         int64_t target = ct0 + vc.CS;
+        double smin = 0.0;
         const double *trow = vc.rows + ((c * (vc.CS / 32)) + (vc.CS / 32 - 1)) * NT;
         if (spec) {
           const int ntie = vc.ntie[c];
           const int *tl = vc.ties + c * TEHMM_SPEC_MAXT;
+          int kseg = ntie;
           for (int k = 0; k < ntie; ++k) {
             const int64_t tp = ct0 + tl[k];
-            if (tp > g) { target = tp; trow = vc.tierows + (c * TEHMM_SPEC_MAXT + k) * NT; break; }
+            if (tp > g) { target = tp; trow = vc.tierows + (c * TEHMM_SPEC_MAXT + k) * NT; kseg = k; break; }
           }
+          if (SEGMIN) smin = vc.segmin[c * (TEHMM_SPEC_MAXT + 1) + kseg];
           if (pg > 47 || g >= ct0 + vc.CS || target <= cur + CPB) spec = false;
         }
         double wrow = 0.0, wend = 0.0, delta = 0.0;
@@ -295,7 +301,7 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
         } else {
           if (lane == 0) { seqpos[(it + 1) & 3] = cur + np; *gen = it + 1; }
         }
-        const double span = spec ? fabs(vc.gain[c]) * 1.01 + 256.0 : 0.0;
+        const double span = (spec && !SEGMIN) ? fabs(vc.gain[c]) * 1.01 + 256.0 : 0.0;
         for (int p = 0; p < np; ++p) {
           const int64_t t = cur + p;
           const double b = br[p * RS + jl];
@@ -327,7 +333,7 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
             const double d0 = wave_max_live(both_dead ? -INFINITY : d, live);
             const bool same = !live || both_dead || d == d0;
             const bool inb = !live || both_dead || exp_of(-v) == e + 1;   // 2^e <= |v| < 2^(e+1)
-            const double vlow = wave_min_f64(live && !both_dead ? v : 0.0) - span;
+            const double vlow = SEGMIN ? smin + d0 : wave_min_f64(live && !both_dead ? v : 0.0) - span;
             const bool endok = d0 == d0 && d0 > -INFINITY && exp_of(-vlow) == e + 1;
             jump = __all(same && inb) && endok;
             delta = d0;
