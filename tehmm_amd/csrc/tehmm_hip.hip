@@ -745,11 +745,17 @@ static void launch_vit_fix(tehmm_batch *b, const tehmm_model *m, const IntervalT
 // ---- lane = item passes -----------------------------------------------------------------------
 static LaneGeom lane_geom(const LaneWork &lw);
 
-static int lane_sub_size(int CS) {
-  const char *s = std::getenv("TEHMM_LANE_SUB");       // 0 disables; tests use small items
-  int L = s ? std::atoi(s) : 512;
-  if (L <= 0 || CS <= 0) return 0;
-  L = std::max(64, (L + 63) & ~63);
+// Item length L (L | CS, 64 | L).  Every wave owns 64 items; 512 positions per item keep the warm-up
+// overhead below 20 %, 256 are used for small batches so that the 1024 SIMDs still get a wave each.
+// TEHMM_LANE_SUB overrides (0 disables the lane passes).
+static int lane_sub_size(int CS, int64_t total) {
+  if (CS <= 0) return 0;
+  int L = total >= (int64_t)512 * 64 * 1024 ? 512 : 256;
+  if (const char *s = std::getenv("TEHMM_LANE_SUB")) {
+    L = std::atoi(s);
+    if (L <= 0) return 0;
+    L = std::max(64, (L + 63) & ~63);
+  }
   if (L > CS || CS % L != 0) L = CS;
   return L;
 }
@@ -852,11 +858,11 @@ static void launch_vit_lane(tehmm_batch *b, const tehmm_model *m, const Interval
   const VitItems vi = lane_vit_items(lw);
   if (n_work <= 0) return;
   const dim3 grid((n_work + 3) / 4);
-  if (quant)
+  if (quant) {
     hipLaunchKernelGGL((k_vit_lane<NT, true>), grid, dim3(256), 0, st, iv, lg, vc, vi, m->N, Wu,
                        (const int *)lw.wk_g.p, (const int *)lw.wk_e.p, n_work, (const double *)lw.qtabs.p, e0,
                        (const double *)lw.B.p, b->tb.p);
-  else
+  } else
     hipLaunchKernelGGL((k_vit_lane<NT, false>), grid, dim3(256), 0, st, iv, lg, vc, vi, m->N, Wu,
                        (const int *)nullptr, (const int *)nullptr, n_work, (const double *)m->ltG.p, 0,
                        (const double *)lw.B.p, b->tb.p);
@@ -991,8 +997,11 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   LaneWork &lw = b->lw;
   const EmisTab emg = without_lds_tables(em);
   const int eV = 0, eP = 5;
-  const int LS = (vspec || fspec) ? lane_sub_size(CS) : 0;
-  const bool vlane = vspec && LS > 0, flane = fspec && LS > 0;
+  const int LS = ((vspec || fspec) && m->NP <= 36) ? lane_sub_size(CS, b->total) : 0;   // 4 * NP VGPRs of state
+  // The lane = item Viterbi passes are opt-in (TEHMM_LANE_VIT=1): bit-exact, but on gfx950 their quantised
+  // pass is instruction-fetch bound and not yet faster than the lane = state pass.
+  const char *lvs = std::getenv("TEHMM_LANE_VIT");
+  const bool vlane = vspec && LS > 0 && lvs && std::atoi(lvs) != 0, flane = fspec && LS > 0;
   const char *wus = std::getenv("TEHMM_LANE_WARMUP");
   const int WuF = std::min(LS, std::max(1, wus ? std::atoi(wus) : 96));       // forward / backward warm-up
   const int WuV = std::min(LS, 64);                                            // Viterbi warm-up (multiple of 32)
@@ -1161,6 +1170,16 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
             else if (!dup) he[(size_t)(sw.h_first[id] + lw.h_t0[item] / CS)] = TEHMM_SPEC_NONE;
           }
         }
+      }
+      {
+        // waves of one binade next to each other: they share one quantised table in the scalar cache
+        std::vector<int> ord(wk_g.size());
+        std::iota(ord.begin(), ord.end(), 0);
+        std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return wk_e[(size_t)x] < wk_e[(size_t)y]; });
+        std::vector<int> g2(ord.size()), e2(ord.size());
+        for (size_t i = 0; i < ord.size(); ++i) { g2[i] = wk_g[(size_t)ord[i]]; e2[i] = wk_e[(size_t)ord[i]]; }
+        wk_g.swap(g2);
+        wk_e.swap(e2);
       }
       const int n_work = (int)wk_g.size();
       if (n_work > 0) {

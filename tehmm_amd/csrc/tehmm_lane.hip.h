@@ -112,30 +112,42 @@ void k_fb_lane(IntervalTab iv, LaneGeom lg, int N, int CS, int Wu, const double 
   for (int j = 0; j < NT; ++j) v[j] = DIR == 0 ? (j < N ? 1.0 / (double)N : 0.0) : 0.0;
   double slog = 0.0;
 
-  // out[o] = sum_f v[f] * tab[f][o]
-  // (the table offset is laundered every step: hoisting 1296 loop-invariant scalar loads out of the
-  // position loop would spill thousands of SGPRs; re-issued s_loads hit the scalar cache)
-  // out[o] = sum_f v[f] * tab[f][o]
-  // (the table offset is laundered every step: hoisting 1296 loop-invariant scalar loads out of the
-  // position loop would spill thousands of SGPRs; re-issued s_loads hit the scalar cache)
+  // out[o] = sum_f v[f] * tab[f][o], as a pinned software pipeline over the scalar stream.  SMEM answers
+  // out of order, so a wait is always for ALL outstanding loads: block b + 1 (4 table rows x 4 outputs
+  // = 16 doubles = two s_load_dwordx16) is therefore requested only AFTER the first FMA of block b has
+  // waited for block b's operands (the empty asm makes the request depend on that FMA), and it
+  // arrives while the other 15 FMAs run.  The scheduling barrier keeps the blocks apart; the pointer
+  // is laundered every step so that nothing is hoisted out of the position loop.
   auto matvec = [&](double (&acc)[NT]) {
-    int z = 0;
-    asm volatile("" : "+s"(z));
-    const_f64 *tp = (const_f64 *)(size_t)tab + z;
+    const_f64 *tp = (const_f64 *)(size_t)tab;
+    asm volatile("" : "+s"(tp));
+    constexpr int BLK = 16, NB = NT * NT / BLK;
+    double t[2][BLK];
 #pragma unroll
-    for (int og = 0; og < NT / 4; ++og) {
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int i = 0; i < BLK; ++i) t[0][i] = tp[i];
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int f = 0; f < NT; ++f) {
-        a0 = fma(v[f], tp[(og * NT + f) * 4 + 0], a0);
-        a1 = fma(v[f], tp[(og * NT + f) * 4 + 1], a1);
-        a2 = fma(v[f], tp[(og * NT + f) * 4 + 2], a2);
-        a3 = fma(v[f], tp[(og * NT + f) * 4 + 3], a3);
+    for (int b = 0; b < NB; ++b) {
+      const int og = (b * 4) / NT, f0 = (b * 4) % NT;
+      const double *tc = t[b & 1];
+      double *tn = t[(b + 1) & 1];
+      a[0] = fma(v[f0], tc[0], a[0]);
+      const_f64 *tq = tp;
+      asm volatile("" : "+s"(tq) : "v"(a[0]));
+      if (b + 1 < NB) {
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) tn[i] = tq[(b + 1) * BLK + i];
       }
-      acc[4 * og] = a0;
-      acc[4 * og + 1] = a1;
-      acc[4 * og + 2] = a2;
-      acc[4 * og + 3] = a3;
+#pragma unroll
+      for (int i = 1; i < BLK; ++i) a[i & 3] = fma(v[f0 + (i >> 2)], tc[i], a[i & 3]);
+      if (f0 + 4 == NT) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[4 * og + q] = a[q];
+          a[q] = 0.0;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   auto expo = [&](const double (&a)[NT]) {
@@ -411,25 +423,128 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, VitChunks vc, VitItems vi, int N, i
     base = 0.0;
     pmin = INFINITY;
   };
-  // one position: s = position relative to t0 (negative: warm-up), bp = its emission row.  The row is
-  // read twice (tie scan, then update) so that it never has to sit in registers next to W and x.
-  auto step = [&](const double *bp, int s) {
-    const bool official = s >= 0;
-    bool tie = false;
-    if (QUANT) {
+  // One position: s = position relative to t0 (negative: warm-up), bp = its emission row, bpn = the row
+  // of the next position.  Outputs are finished four at a time; the four emission values of a group are
+  // requested one group ahead (bnx: the first group of a step during the last group of the step
+  // before), so the row is read once and its latency hides behind a group of max-plus work.  The old
+  // vector stays intact until the end of the step, which is when a rounding tie found on the way is
+  // recorded.
+  double bnx[4];
+  bool pending = false;
+  auto prefetch = [&](const double *row, int og) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const double bj = bp[(int64_t)j << 6];
-        const double q = (bj + M) - M;
-        if (j == 0) bad = bad || bj != bj;
-        if ((j < NT - 8 || j < N) && fabs(bj - q) == half_u) tie = true;
+    for (int q = 0; q < 4; ++q) bnx[q] = row[(int64_t)(4 * og + q) << 6];
+  };
+  auto step = [&](const double *bp, const double *bpn, int s) {
+    const bool official = s >= 0;
+    double tmin = 1.0;
+    // the max-plus recurrence as a pinned software pipeline over the scalar stream (see k_fb_lane)
+    const_f64 *tp = tab0;
+    asm volatile("" : "+s"(tp));
+    constexpr int BLK = 16, NB = NT * NT / BLK;
+    double t[2][BLK];
+#pragma unroll
+    for (int i = 0; i < BLK; ++i) t[0][i] = tp[i];
+    double Wn[NT];
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
+    double bc[4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int og = (b * 4) / NT, f0 = (b * 4) % NT;
+      const double *tc = t[b & 1];
+      double *tn = t[(b + 1) & 1];
+      if (f0 == 0) {
+        // x = max_f W[f] + tab[f][o]   (tab scalar; QUANT: it carries the from-index in its low bits)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bc[q] = bnx[q];
+        if (og + 1 < NT / 4) prefetch(bp, og + 1);
+        else prefetch(bpn, 0);
+        x0 = W[0] + tc[0];
+      } else {
+        x0 = fmax(x0, W[f0] + tc[0]);
       }
-      if (__any(tie && run)) {
-        // a rounding tie at this position: close the piece (record W_{t-1}); the vector restarts from
-        // zeros behind it and the exact chain handles the position itself
-        if (tie && run && official) {
+      const_f64 *tq = tp;
+      asm volatile("" : "+s"(tq) : "v"(x0));
+      if (b + 1 < NB) {
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) tn[i] = tq[(b + 1) * BLK + i];
+      }
+      if (f0 == 0) {
+        x1 = W[0] + tc[1];
+        x2 = W[0] + tc[2];
+        x3 = W[0] + tc[3];
+      } else {
+        x1 = fmax(x1, W[f0] + tc[1]);
+        x2 = fmax(x2, W[f0] + tc[2]);
+        x3 = fmax(x3, W[f0] + tc[3]);
+      }
+#pragma unroll
+      for (int r = 1; r < 4; ++r) {
+        x0 = fmax(x0, W[f0 + r] + tc[4 * r + 0]);
+        x1 = fmax(x1, W[f0 + r] + tc[4 * r + 1]);
+        x2 = fmax(x2, W[f0 + r] + tc[4 * r + 2]);
+        x3 = fmax(x3, W[f0 + r] + tc[4 * r + 3]);
+      }
+      if (f0 + 4 < NT) {
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
+      const double xs[4] = {x0, x1, x2, x3};
+      uint32_t pw = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int o = 4 * og + q;
+        const double bo = bc[q];
+        if (o == 0) bad = bad | (bo != bo);                   // (bitwise: no control flow in this body)
+        if (QUANT) {
+          // xs = 64 * (best value) + (63 - first arg-max) * u  (exact)
+          const double bq = (bo + M) - M;
+          // tie <=> |b - R_u(b)| == u/2 for some state: tracked as a running minimum of the distance to
+          // u/2 (one compare per step; 36 compares would each occupy a scalar mask).  Pads hold b = 0.
+          tmin = fmin(tmin, fabs(fabs(bo - bq) - half_u));
+          const double m = xs[q];
+          const double k = m * inv_u;                          // m / u, an integer
+          const double r = k - 64.0 * floor(k * 0.015625);     // k mod 64 in [0, 63]
+          const int arg = 63 - (int)r;
+          // a dead state (m = -inf) makes r NaN: maxNum(NaN, -inf) puts -inf back without a branch
+          Wn[o] = fmax((m - r * u) + 64.0 * bq, -INFINITY);
+          pw |= (uint32_t)(arg & 63) << (8 * q);
+        } else {
+          Wn[o] = xs[q] + bo;
+        }
+      }
+      // traceback bytes of this group (a tie position gets garbage: the exact chain rewrites it)
+      if (QUANT && run && official) tb32[(p0 + t0 + s) * (NT / 4) + og] = pw;
+      // pin the tie reduction to its group: left to itself the scheduler sinks all 36 of them to the end
+      // of the step and keeps the whole emission row alive for it
+      if (QUANT) asm volatile("" : "+v"(tmin));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const bool tie = QUANT && tmin == 0.0;
+    if (QUANT) {
+      // a rounding tie at this position: the vector is NOT advanced (W stays W_{t-1}); the next step
+      // records it, closes the piece and restarts from zeros (see `pending` below)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) W[j] = tie ? W[j] : Wn[j];
+      pending = tie;
+      double wl = INFINITY;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wl = fmin(wl, (j < NT - 8 || j < N) ? W[j] : INFINITY);
+      if (!tie) pmin = fmin(pmin, wl * 0.015625 + base);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) W[j] = Wn[j];
+    }
+  };
+  // the tie found at position s - 1: close the piece (record W_{s-2}... i.e. the row of the position before
+  // the tie), restart from zeros behind it; the exact chain handles the tie position itself
+  auto close_piece = [&](int s) {
+    if (!QUANT) return;
+    if (__any(pending)) {
+      if (pending) {
+        if (run && s - 1 >= 0) {
           if (nt < TEHMM_LANE_MAXTI) {
-            vi.ties[item * TEHMM_LANE_MAXTI + nt] = s;
+            vi.ties[item * TEHMM_LANE_MAXTI + nt] = s - 1;
             double *tr = vi.tierows + (item * TEHMM_LANE_MAXTI + nt) * NT;
 #pragma unroll
             for (int j = 0; j < NT; ++j) tr[j] = W[j] * 0.015625 + base;
@@ -437,64 +552,9 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, VitChunks vc, VitItems vi, int N, i
           }
           ++nt;
         }
+        restart();
       }
-    }
-    // Wn[o] = max_f W[f] + tab[f][o]  (+ emission), four outputs at a time (tab scalar; QUANT: it carries
-    // the from-index in its low bits)
-    int z = 0;
-    asm volatile("" : "+s"(z));
-    const_f64 *tp = tab0 + z;
-    double Wn[NT];
-    uint32_t pk[NT / 4];
-#pragma unroll
-    for (int og = 0; og < NT / 4; ++og) {
-      double x0 = W[0] + tp[(og * NT) * 4 + 0], x1 = W[0] + tp[(og * NT) * 4 + 1];
-      double x2 = W[0] + tp[(og * NT) * 4 + 2], x3 = W[0] + tp[(og * NT) * 4 + 3];
-#pragma unroll
-      for (int f = 1; f < NT; ++f) {
-        x0 = fmax(x0, W[f] + tp[(og * NT + f) * 4 + 0]);
-        x1 = fmax(x1, W[f] + tp[(og * NT + f) * 4 + 1]);
-        x2 = fmax(x2, W[f] + tp[(og * NT + f) * 4 + 2]);
-        x3 = fmax(x3, W[f] + tp[(og * NT + f) * 4 + 3]);
-      }
-      const double xs[4] = {x0, x1, x2, x3};
-      uint32_t pw = 0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int o = 4 * og + q;
-        const double bo = bp[(int64_t)o << 6];
-        if (QUANT) {
-          // xs = 64 * (best value) + (63 - first arg-max) * u  (exact)
-          const double bq = 64.0 * ((bo + M) - M);
-          const double m = xs[q];
-          const double k = m * inv_u;                          // m / u, an integer
-          const double r = k - 64.0 * floor(k * 0.015625);     // k mod 64 in [0, 63]
-          const int arg = 63 - (int)r;
-          // a dead state (m = -inf) makes r NaN: maxNum(NaN, -inf) puts -inf back without a branch
-          Wn[o] = fmax((m - r * u) + bq, -INFINITY);
-          pw |= (uint32_t)(arg & 63) << (8 * q);
-        } else {
-          if (o == 0) bad = bad || bo != bo;
-          Wn[o] = xs[q] + bo;
-        }
-      }
-      pk[og] = pw;
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) W[j] = Wn[j];
-    if (QUANT) {
-      if (run && official && !tie) {
-        uint32_t *dst = tb32 + (p0 + t0 + s) * (NT / 4);
-#pragma unroll
-        for (int d = 0; d < NT / 4; ++d) dst[d] = pk[d];
-      }
-      if (__any(tie)) {
-        if (tie) restart();
-      }
-      double wl = INFINITY;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) wl = fmin(wl, (j < NT - 8 || j < N) ? W[j] : INFINITY);
-      if (!tie) pmin = fmin(pmin, wl * 0.015625 + base);
+      pending = false;
     }
   };
   // re-base so that the index bits keep fitting; QUANT records the row of an official position
@@ -530,14 +590,20 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, VitChunks vc, VitItems vi, int N, i
 
   double g0 = 0.0;
   for (int s = -Wu; s < L; ++s) {                       // one loop: the unrolled step exists once
+    close_piece(s);
     if (s == 0) {
       if (run) vec_out(vi.pre);
       pmin = INFINITY;
       if (!QUANT) g0 = vec_max();
     }
-    step(B + (s < 0 ? lane_row(lg, NT, nb, L + s) : lane_row(lg, NT, item, s)), s);
+    const double *bp = B + (s < 0 ? lane_row(lg, NT, nb, L + s) : lane_row(lg, NT, item, s));
+    const int sn = min(s + 1, L - 1);
+    const double *bpn = B + (sn < 0 ? lane_row(lg, NT, nb, L + sn) : lane_row(lg, NT, item, sn));
+    if (s == -Wu) prefetch(bp, 0);
+    step(bp, bpn, s);
     if (((s + Wu) & 31) == 31) rebase(s);
   }
+  close_piece(L);
   if (run) {
     vec_out(vi.end);
     if (QUANT) {
