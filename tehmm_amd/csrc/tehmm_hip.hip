@@ -487,9 +487,13 @@ int tehmm_batch_create(int n, const int64_t *offsets, int K, const uint8_t *obs,
     up(hipGetLastError());
     up(hipDeviceSynchronize());
   }
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->sV, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->sP, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->sB, hipStreamNonBlocking);
+  // the Viterbi pipeline is the longer one: its stream gets the higher dispatch priority so that the
+  // wide posterior kernels fill in around it instead of delaying it
+  int prio_lo = 0, prio_hi = 0;
+  if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->sV, hipStreamNonBlocking, prio_hi);
+  if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->sP, hipStreamNonBlocking, prio_lo);
+  if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->sB, hipStreamNonBlocking, prio_lo);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&b->evX[0], hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&b->evX[1], hipEventDisableTiming);
   for (int i = 0; i < 16 && e == hipSuccess; ++i) {
@@ -997,7 +1001,15 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   LaneWork &lw = b->lw;
   const EmisTab emg = without_lds_tables(em);
   const int eV = 0, eP = 5;
-  const int LS = ((vspec || fspec) && m->NP <= 36) ? lane_sub_size(CS, b->total) : 0;   // 4 * NP VGPRs of state
+  int LS = ((vspec || fspec) && m->NP <= 36) ? lane_sub_size(CS, b->total) : 0;   // 4 * NP VGPRs of state
+  if (LS > 0 && !b->lw.AL.p && !b->lw.B.p) {
+    // the item-interleaved buffers (emission rows, alpha', beta': 3-4 x 8 * NP bytes per position) must
+    // fit next to the results; otherwise stay with the [T][N] speculative passes
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const double need = (double)b->total * m->NP * 8.0 * 4.2;
+    if (need > 0.85 * (double)free_b) LS = 0;
+  }
   // The lane = item Viterbi passes are opt-in (TEHMM_LANE_VIT=1): bit-exact, but on gfx950 their quantised
   // pass is instruction-fetch bound and not yet faster than the lane = state pass.
   const char *lvs = std::getenv("TEHMM_LANE_VIT");
@@ -1008,19 +1020,27 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   VitChunks vc;
   std::vector<double> gain;
   if (vit) (void)hipEventRecord(b->ev[eV], b->sV);
-  if (postr) (void)hipEventRecord(b->ev[eP], b->sP);
   if (vlane || flane) {
-    // emission rows of every position, once, item-interleaved (log rows for Viterbi, linear for fwd/bwd)
     rc = lane_prepare(b, m, CS, LS, flane, vlane);
     if (rc) return rc;
-    hipStream_t st = vlane ? b->sV : b->sP;
+  }
+  // Scheduling.  The speculative Viterbi passes, the emission rows, the forward / backward lane passes
+  // and the combine are throughput kernels that each fill the GPU; the fix-up chains and the traceback
+  // are latency kernels on a few CUs.  With both requested, the Viterbi passes go first and the
+  // posterior pipeline is released behind them (event), so that its wide kernels run next to the
+  // Viterbi fix-up chain instead of competing with the passes that chain is waiting for.
+  const bool defer_post = vit && postr && vspec && !vlane;
+  if (postr && !defer_post) (void)hipEventRecord(b->ev[eP], b->sP);
+  if (vlane) {
+    // emission rows of every position, once, item-interleaved (log rows for Viterbi, linear for fwd/bwd)
+    hipStream_t st = b->sV;
 #define CALL(NT_) launch_emis_lane<NT_>(b, m, iv, emg, vlane, flane, st)
     TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
-    if (vlane) (void)hipEventRecord(b->ev[eV + 4], st);
+    (void)hipEventRecord(b->ev[eV + 4], st);
     if (flane) {
       (void)hipEventRecord(b->evX[0], st);
-      if (vlane) (void)hipStreamWaitEvent(b->sP, b->evX[0], 0);
+      (void)hipStreamWaitEvent(b->sP, b->evX[0], 0);
       (void)hipEventRecord(b->ev[eP + 4], b->sP);
     }
   }
@@ -1044,8 +1064,15 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       HIPCHK(hipMemcpyAsync(gain.data(), sw.gain.p, gain.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     }
   }
-  if (postr) {
+  auto enqueue_posterior = [&]() -> int {
     hipStream_t st = b->sP;
+    if (flane && !vlane) {
+      // emission rows (linear domain) for the forward / backward lane passes
+#define CALL(NT_) launch_emis_lane<NT_>(b, m, iv, emg, false, true, st)
+      TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+      (void)hipEventRecord(b->ev[eP + 4], st);
+    }
     if (flane) {
       // lane = item passes (forward, backward, links), then the two sequential chains on the
       // item-interleaved rows, then the transposing combine
@@ -1110,6 +1137,11 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     } else if (SPL == 1) launch_posterior<1>(b, m, iv, em, st, b->ev[eP + 1]);
     else launch_posterior<2>(b, m, iv, em, st, b->ev[eP + 1]);
     (void)hipEventRecord(b->ev[eP + 2], st);
+    return TEHMM_OK;
+  };
+  if (postr && !defer_post) {
+    rc = enqueue_posterior();
+    if (rc) return rc;
   }
   if (vit) {
     hipStream_t st = b->sV;
@@ -1213,6 +1245,12 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
       (void)hipEventRecord(b->ev[eV + 3], st);
+      if (defer_post) {
+        (void)hipStreamWaitEvent(b->sP, b->ev[eV + 3], 0);
+        (void)hipEventRecord(b->ev[eP], b->sP);
+        rc = enqueue_posterior();
+        if (rc) return rc;
+      }
 #define CALL(NT_) launch_vit_fix<NT_>(b, m, iv, em, vc, false, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
