@@ -151,12 +151,17 @@ def main():
         value = pos_per_step * args.steps / dt
         kavg = {k: float(np.mean(v)) for k, v in kt.items()}
         dom = max(kavg, key=kavg.get)
-        # algorithmic bytes per position of each kernel:
-        #   viterbi: obs in (K) + int64 path out (8);  backward_posterior: obs in (K) + posterior
-        #   row out (8N);  forward: obs in (K);  traceback: path out (8)
-        alg = {"viterbi": K + 8, "backward_posterior": K + 8 * N, "forward": K, "traceback": 8,
-               "forward_backward": K, "posterior_combine": 8 * N, "viterbi_speculate": K,
-               "forward_backward_speculate": K + 16 * N}
+        # algorithmic bytes per position of each stage (API-level I/O only, the
+        # intermediate lattices / emission rows / traceback tables do not count):
+        #   viterbi*: obs in (K) [+ int64 path out (8) where the stage produces it];  forward*: obs in
+        #   (K);  posterior_combine / backward_posterior: posterior row out (8N);  traceback: path out (8)
+        alg = {"viterbi": K + 8, "viterbi_speculate": K, "traceback": 8, "emission_rows": K,
+               "forward_backward_speculate": K, "forward_backward": K, "forward": K,
+               "posterior_combine": 8 * N, "backward_posterior": K + 8 * N}
+        # fp64 VALU operations per position of each stage (the resource that actually binds):
+        #   max-plus pass: N*N (add + max);  forward or backward pass: N*N fma = 2 N*N flop
+        flop = {"viterbi_speculate": 2 * 2 * N * N, "viterbi": 2 * N * N, "forward_backward_speculate": 2 * 2 * N * N,
+                "forward_backward": 2 * 2 * N * N, "forward": 2 * N * N, "backward_posterior": 2 * N * N}
         achieved = alg[dom] * float(total) / (kavg[dom] * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
@@ -179,7 +184,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "alg_bytes_per_position": alg[dom],
-                         "whole_path_GBps": (K + 8 + 8 * N) * value / world / 1e9},
+                         "whole_path_GBps": (K + 8 + 8 * N) * value / world / 1e9,
+                         # what binds instead of HBM: fp64 vector issue (78.6 TFLOP/s peak on MI355X)
+                         "valu_f64": {"achieved": flop.get(dom, 0) * float(total) / (kavg[dom] * 1e-3) / 1e12,
+                                      "peak": 78.6, "unit": "TFLOP/s",
+                                      "frac": flop.get(dom, 0) * float(total) / (kavg[dom] * 1e-3) / 1e12 / 78.6}},
             "kernel_ms": kavg,
         }
         if world == 1 and not args.no_extra:

@@ -275,3 +275,49 @@ def test_fused_random_shapes(hip, seed):
     assert_allclose(start, ref["start"], rtol=RTOL, atol=1e-12)
     assert_allclose(trans, ref["trans"], rtol=RTOL, atol=1e-12)
     assert_allclose(st, ref["obs"], rtol=RTOL, atol=1e-12)
+
+
+CHUNK_CONFIGS = [
+    {"TEHMM_SPEC_CHUNK": "0"},                                                  # cooperative kernels only
+    {"TEHMM_SPEC_CHUNK": "128", "TEHMM_LANE_SUB": "0"},                         # lane = state speculation
+    {"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "64"},                        # lane = item fwd/bwd
+    {"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "128", "TEHMM_LANE_WARMUP": "24"},   # short warm-up: links fail
+    {"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "64", "TEHMM_LANE_VIT": "1"},  # lane = item Viterbi too
+    {"TEHMM_SPEC_CHUNK": "512", "TEHMM_LANE_SUB": "256", "TEHMM_LANE_VIT": "1"},
+]
+
+
+@pytest.mark.parametrize("cfg", range(len(CHUNK_CONFIGS)))
+@pytest.mark.parametrize("N", [35, 20, 7])
+def test_chunk_parallel_paths(hip, monkeypatch, cfg, N):
+    """Every chunk-parallel code path (exact speculative Viterbi, speculative forward / backward,
+    lane = item passes, their fix-up chains, jumps, ties, failed links) at chunk sizes small enough for
+    the oracle: Viterbi paths and scores bit-exact, posteriors / log-likelihoods to 1e-6."""
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    from oracle import oracle
+    for k in ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_LANE_VIT"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in CHUNK_CONFIGS[cfg].items():
+        monkeypatch.setenv(k, v)
+    model = synth.make_model(N, seed=3 + N)
+    rs = np.random.RandomState(77 + cfg + N)
+    lens = [int(x) for x in rs.choice([1, 63, 300, 1024, 2500, 4097, 6000, 9000], size=6)] + [20000, 45000]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = synth.sample_obs(model, int(offs[-1]), seed=cfg, missing=0.03)
+    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, 1.0, model.symbols_per_track)
+    hb = HipBatch(obs, offs)
+    for _ in range(2):                      # second call reuses the chunk / item workspaces
+        res = hm.eval(hb, viterbi=True, posterior=True)
+    p_o, vlp_o, flp_o, post_o = oracle.eval_batch(obs, offs, model.log_probs, model.log_startprob,
+                                                  model.log_transmat, 1.0, None, n_threads=4)
+    assert_array_equal(hb.paths(), p_o)
+    assert_array_equal(res["viterbi_logprob"], vlp_o)
+    assert_allclose(res["forward_logprob"], flp_o, rtol=RTOL)
+    assert_allclose(hb.posteriors(), post_o, rtol=RTOL, atol=1e-15)
+    t = hb.timing()
+    if CHUNK_CONFIGS[cfg]["TEHMM_SPEC_CHUNK"] != "0":
+        # the long intervals reach |V| >= 2^18, so chunks really are jumped over (not just run exactly)
+        assert "viterbi_speculate" in t and t["count:viterbi_exact_blocks"] > 0
+        assert t["count:viterbi_chunk_jumps"] > 0
+        assert t["count:forward_chunk_jumps"] > 0 and t["count:backward_chunk_jumps"] > 0
