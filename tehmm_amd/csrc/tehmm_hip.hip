@@ -683,7 +683,7 @@ static int spec_prepare(tehmm_batch *b, const tehmm_model *m, int CS) {
   HIPCHK(sw.wstart.alloc(nc * (size_t)m->NP));
   HIPCHK(sw.gain.alloc(nc));
   HIPCHK(sw.wmin.alloc(nc));
-  HIPCHK(sw.rows.alloc(nc * (size_t)(CS / 32) * m->NP));
+  HIPCHK(sw.rows.alloc(nc * (size_t)(CS / TEHMM_VROW) * m->NP));
   HIPCHK(sw.ntie.alloc(nc));
   HIPCHK(sw.ties.alloc(nc * TEHMM_SPEC_MAXT));
   HIPCHK(sw.tierows.alloc(nc * TEHMM_SPEC_MAXT * (size_t)m->NP));
@@ -704,7 +704,8 @@ static void spec_assign_binades(const tehmm_batch *b, const std::vector<double> 
       v = ve;
       const bool full = sw.h_t0[(size_t)c] + sw.CS <= b->h_len[i];
       if (c == sw.h_first[i] || !full || !(g == g) || !(g < 0.0)) continue;
-      const double margin = 512.0 + 2e-3 * std::fabs(ve);
+      static const double rel = std::getenv("TEHMM_SPEC_MARGIN") ? std::atof(std::getenv("TEHMM_SPEC_MARGIN")) : 5e-4;
+      const double margin = 512.0 + rel * std::fabs(ve);
       const double lo = std::fabs(vs) - margin, hi = std::fabs(ve) + margin;
       if (!(lo > 0.0)) continue;
       int ex = 0;
@@ -1028,9 +1029,10 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   // and the combine are throughput kernels that each fill the GPU; the fix-up chains and the traceback
   // are latency kernels on a few CUs.  With both requested, the Viterbi passes go first and the
   // posterior pipeline is released behind them (event), so that its wide kernels run next to the
-  // Viterbi fix-up chain instead of competing with the passes that chain is waiting for.
+  // Viterbi fix-up chain instead of competing with the passes that chain is waiting for (its emission
+  // rows, which depend on nothing, are computed up front).
   const bool defer_post = vit && postr && vspec && !vlane;
-  if (postr && !defer_post) (void)hipEventRecord(b->ev[eP], b->sP);
+  if (postr) (void)hipEventRecord(b->ev[eP], b->sP);
   if (vlane) {
     // emission rows of every position, once, item-interleaved (log rows for Viterbi, linear for fwd/bwd)
     hipStream_t st = b->sV;
@@ -1064,15 +1066,19 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       HIPCHK(hipMemcpyAsync(gain.data(), sw.gain.p, gain.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     }
   }
-  auto enqueue_posterior = [&]() -> int {
-    hipStream_t st = b->sP;
+  auto enqueue_emission = [&]() {
     if (flane && !vlane) {
       // emission rows (linear domain) for the forward / backward lane passes
+      hipStream_t st = b->sP;
 #define CALL(NT_) launch_emis_lane<NT_>(b, m, iv, emg, false, true, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
       (void)hipEventRecord(b->ev[eP + 4], st);
     }
+  };
+  auto enqueue_posterior = [&]() -> int {
+    hipStream_t st = b->sP;
+    (void)hipEventRecord(b->ev[10], st);            // start of the passes (behind any deferral wait)
     if (flane) {
       // lane = item passes (forward, backward, links), then the two sequential chains on the
       // item-interleaved rows, then the transposing combine
@@ -1139,7 +1145,9 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     (void)hipEventRecord(b->ev[eP + 2], st);
     return TEHMM_OK;
   };
+  if (postr && defer_post) enqueue_emission();      // the emission rows do not wait (17 ms next to P0)
   if (postr && !defer_post) {
+    enqueue_emission();
     rc = enqueue_posterior();
     if (rc) return rc;
   }
@@ -1247,7 +1255,6 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       (void)hipEventRecord(b->ev[eV + 3], st);
       if (defer_post) {
         (void)hipStreamWaitEvent(b->sP, b->ev[eV + 3], 0);
-        (void)hipEventRecord(b->ev[eP], b->sP);
         rc = enqueue_posterior();
         if (rc) return rc;
       }
@@ -1297,7 +1304,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
         b->tpairs.push_back({eP, eP + 4});
       }
       b->tnames.push_back("forward_backward_speculate");
-      b->tpairs.push_back({eP + 4, eP + 3});
+      b->tpairs.push_back({10, eP + 3});
       b->tnames.push_back("forward_backward");
       b->tpairs.push_back({eP + 3, eP + 1});
     } else if (fspec) {

@@ -557,21 +557,24 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, VitChunks vc, VitItems vi, int N, i
       pending = false;
     }
   };
-  // re-base so that the index bits keep fitting; QUANT records the row of an official position
-  auto rebase = [&](int s) {
+  // every 16th position: QUANT records the row of an official position; every 32nd it first re-bases so
+  // that the index bits keep fitting
+  auto rebase = [&](int s, bool do_rebase) {
     if (!QUANT) return;
-    double mx = W[0];
+    if (do_rebase) {
+      double mx = W[0];
 #pragma unroll
-    for (int j = 1; j < NT; ++j) mx = fmax(mx, W[j]);
-    if (mx > -INFINITY) {
+      for (int j = 1; j < NT; ++j) mx = fmax(mx, W[j]);
+      if (mx > -INFINITY) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) W[j] -= mx;
-      base += mx * 0.015625;
-    } else {
-      bad = true;
+        for (int j = 0; j < NT; ++j) W[j] -= mx;
+        base += mx * 0.015625;
+      } else {
+        bad = true;
+      }
     }
     if (s >= 0 && run) {
-      double *row = vc.rows + ((int64_t)c * (CS / 32) + (t0 - ct0 + s) / 32) * NT;
+      double *row = vc.rows + ((int64_t)c * (CS / TEHMM_VROW) + (t0 - ct0 + s) / TEHMM_VROW) * NT;
 #pragma unroll
       for (int j = 0; j < NT; ++j) row[j] = W[j] * 0.015625 + base;
     }
@@ -601,7 +604,7 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, VitChunks vc, VitItems vi, int N, i
     const double *bpn = B + (sn < 0 ? lane_row(lg, NT, nb, L + sn) : lane_row(lg, NT, item, sn));
     if (s == -Wu) prefetch(bp, 0);
     step(bp, bpn, s);
-    if (((s + Wu) & 31) == 31) rebase(s);
+    if (((s + Wu) & (TEHMM_VROW - 1)) == TEHMM_VROW - 1) rebase(s, ((s + Wu) & 31) == 31);
   }
   close_piece(L);
   if (run) {
@@ -636,7 +639,7 @@ __global__ __launch_bounds__(256) void k_vit_stitch(IntervalTab iv, LaneGeom lg,
   }
   const int id = vc.iv[c];
   const int64_t ct0 = vc.t0[c];
-  const int L = lg.L, SUB = vc.CS / L, R = L / 32;
+  const int L = lg.L, SUB = vc.CS / L, R = L / TEHMM_VROW;
   const int64_t item0 = lg.ifirst[id] + ct0 / L;
   const bool live = lane < N;
   const int jl = min(lane, NT - 1);
@@ -672,8 +675,8 @@ __global__ __launch_bounds__(256) void k_vit_stitch(IntervalTab iv, LaneGeom lg,
     const int nti = min(vi.ntie[item], TEHMM_LANE_MAXTI);
     const int first_tie = nti > 0 ? vi.ties[item * TEHMM_LANE_MAXTI] : L;
     if (off != 0.0 && lane < NT) {
-      for (int m = 0; m < R && 32 * m + 31 < first_tie; ++m)
-        vc.rows[((int64_t)c * (vc.CS / 32) + k * R + m) * NT + lane] += off;
+      for (int m = 0; m < R && TEHMM_VROW * m + TEHMM_VROW - 1 < first_tie; ++m)
+        vc.rows[((int64_t)c * (vc.CS / TEHMM_VROW) + k * R + m) * NT + lane] += off;
     }
     segmin = fmin(segmin, vi.piecemin[item * (TEHMM_LANE_MAXTI + 1)] + off);
     for (int i = 0; i < nti; ++i) {

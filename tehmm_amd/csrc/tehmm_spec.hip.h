@@ -47,13 +47,14 @@ struct VitChunks {
   double *gain;           // P0: max_j W_end of the chunk started from zeros
   int *ok;                // P2: 1 = the speculative results of the chunk are usable
   double *wmin;           // P2: most negative W (relative to the zero start) seen in the chunk
-  double *rows;           // P2: [chunk][CS/32][NT] W rows at positions t0 + 32k + 31
+  double *rows;           // P2: [chunk][CS/16][NT] W rows at positions t0 + 16k + 15
   int *ntie;              // P2: number of tie positions in the chunk (> TEHMM_SPEC_MAXT: unusable)
   int *ties;              // P2: [chunk][MAXT] tie positions relative to t0, ascending
   double *tierows;        // P2: [chunk][MAXT][NT] W row of the position just before each tie
   double *segmin;         // lane passes: [chunk][MAXT + 1] lowest live W of each segment (its frame)
 };
 #define TEHMM_SPEC_MAXT 32
+#define TEHMM_VROW 16             // spacing of the recorded W rows
 
 // wave-wide max / min over the live lanes (fp64, shuffle based: used once per 32 steps)
 __device__ __forceinline__ double wave_max_live(double v, bool live) {
@@ -173,17 +174,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             W = fin ? (m - r * u) + b : -INFINITY;
             if (live) tb[(p0 + t) * NT + lane] = (uint8_t)arg;
           }
-          if ((p & 31) == 31) {
-            // re-base so that the index bits keep fitting, record the row
-            const double mx = wave_max_live(W, live);
-            if (mx > -INFINITY) {
-              W -= mx;
-              base += mx * 0.015625;
-            } else {
-              bad = true;                                    // the whole vector died
+          if ((p & (TEHMM_VROW - 1)) == TEHMM_VROW - 1) {
+            if ((p & 31) == 31) {
+              // re-base so that the index bits keep fitting
+              const double mx = wave_max_live(W, live);
+              if (mx > -INFINITY) {
+                W -= mx;
+                base += mx * 0.015625;
+              } else {
+                bad = true;                                  // the whole vector died
+              }
             }
+            // record the row
             if (lane < NT)
-              vc.rows[((int64_t)c * (vc.CS / 32) + (t - t0) / 32) * NT + lane] =
+              vc.rows[((int64_t)c * (vc.CS / TEHMM_VROW) + (t - t0) / TEHMM_VROW) * NT + lane] =
                   live ? W * 0.015625 + base : -INFINITY;
           }
         } else {
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // Exact sequential chain with jumps over verified chunks.  Same roles, rings and arithmetic as
 // k_vit_coop<NT, 64, false> (no segment ratios); the sequence of 64-position blocks is dynamic:
 //   seqpos[it & 3] = first position of the block of iteration `it` (>= T: finished), published by
-//   the chain wave at the 32nd step of the previous block (gen = it) so that the emission wave
+//   the chain wave at the check step of the previous block (gen = it) so that the emission wave
 //   can prepare exactly that block.
 // LDS (doubles): bring [3][64][RS] | Vring [2][65][VS] | ltab [lds_rows][NT] | seq (4 x i64, gen)
 // ------------------------------------------------------------------------------------------
@@ -223,7 +227,7 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
   extern __shared__ double sm[];
   constexpr int RS = NT + 1;
   constexpr int VS = NT + 2;
-  constexpr int CPB = 64;
+  constexpr int CPB = 32;      // short blocks: a tie or a verification costs 32 exact steps, not 64
   double *bring = sm;
   double *Vring = bring + 3 * CPB * RS;
   double *ltab = Vring + 2 * (CPB + 1) * VS;
@@ -277,11 +281,13 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
         const int64_t ct0 = vc.t0[c];
         const int e = vc.e[c];
         bool spec = e != TEHMM_SPEC_NONE && np == CPB && vc.ok[c] != 0;
-        const int64_t g = ct0 + ((cur + 16 - ct0) / 32) * 32 + 31;   // smallest recorded row >= cur + 16
-        const int pg = (int)(g - cur);                          // in-block step of the check, 16..47
+        // smallest recorded row >= cur + 12 (rank convergence takes 3-16 steps; a check that comes too
+        // early simply fails and the next block tries again)
+        const int64_t g = ct0 + ((cur + 12 - ct0) / TEHMM_VROW) * TEHMM_VROW + (TEHMM_VROW - 1);
+        const int pg = (int)(g - cur);                          // in-block step of the check, 12..27
         int64_t target = ct0 + vc.CS;
         double smin = 0.0;
-        const double *trow = vc.rows + ((c * (vc.CS / 32)) + (vc.CS / 32 - 1)) * NT;
+        const double *trow = vc.rows + ((c * (vc.CS / TEHMM_VROW)) + (vc.CS / TEHMM_VROW - 1)) * NT;
         if (spec) {
           const int ntie = vc.ntie[c];
           const int *tl = vc.ties + c * TEHMM_SPEC_MAXT;
@@ -291,12 +297,12 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
             if (tp > g) { target = tp; trow = vc.tierows + (c * TEHMM_SPEC_MAXT + k) * NT; kseg = k; break; }
           }
           if (SEGMIN) smin = vc.segmin[c * (TEHMM_SPEC_MAXT + 1) + kseg];
-          if (pg > 47 || g >= ct0 + vc.CS || target <= cur + CPB) spec = false;
+          if (pg >= CPB || g >= ct0 + vc.CS || target <= cur + CPB) spec = false;
         }
         double wrow = 0.0, wend = 0.0, delta = 0.0;
         bool jump = false;
         if (spec) {
-          wrow = vc.rows[((c * (vc.CS / 32)) + (g - ct0) / 32) * NT + jl];
+          wrow = vc.rows[((c * (vc.CS / TEHMM_VROW)) + (g - ct0) / TEHMM_VROW) * NT + jl];
           wend = trow[jl];
         } else {
           if (lane == 0) { seqpos[(it + 1) & 3] = cur + np; *gen = it + 1; }
