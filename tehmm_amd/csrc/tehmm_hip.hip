@@ -91,6 +91,7 @@ struct tehmm_model {
   double normalize = 1.0;
   DBuf<double> lt, ltT, A, AT, pi, tab, ltab;
   DBuf<double> ltG, AG, ATG;   // output-group-major copies for the lane = item kernels (tehmm_lane.hip.h)
+  DBuf<float> ltP;             // float pairs [o / 2][f][o % 2] for the packed P0 pass
   int rowbase[TEHMM_MAX_TRACKS];
   int rowcnt[TEHMM_MAX_TRACKS];
   int ldsbase[TEHMM_MAX_TRACKS];
@@ -128,6 +129,7 @@ struct LaneWork {
   DBuf<double> B, BH, MS, AL, BE, pre_f, end_f, pre_b, end_b, slog32;
   // Viterbi lane passes
   DBuf<double> vpre, vend, vgain, vtierows, vpiecemin, qtabs;
+  DBuf<float> B32;
   DBuf<int> vbad, vntie, vties, wk_g, wk_e;
 };
 
@@ -384,7 +386,11 @@ int tehmm_model_create(int N, int K, int S, const double *lt, const double *pi,
   };
   const std::vector<double> hltG = group_major(hlt), hAG = group_major(hA), hATG = group_major(hAT);
   hipError_t e = m->lt.upload(hlt.data(), hlt.size());
+  std::vector<float> hltP((size_t)NP * NP);
+  for (int f = 0; f < NP; ++f)
+    for (int o = 0; o < NP; ++o) hltP[((size_t)(o >> 1) * NP + f) * 2 + (o & 1)] = (float)hlt[(size_t)f * NP + o];
   if (e == hipSuccess) e = m->ltG.upload(hltG.data(), hltG.size());
+  if (e == hipSuccess) e = m->ltP.upload(hltP.data(), hltP.size());
   if (e == hipSuccess) e = m->AG.upload(hAG.data(), hAG.size());
   if (e == hipSuccess) e = m->ATG.upload(hATG.data(), hATG.size());
   if (e == hipSuccess) e = m->ltT.upload(hltT.data(), hltT.size());
@@ -765,7 +771,8 @@ static int lane_sub_size(int CS, int64_t total) {
   return L;
 }
 
-static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, bool want_fb, bool want_vit) {
+static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, bool want_fb, bool want_vit,
+                        bool want_gain) {
   LaneWork &lw = b->lw;
   if (lw.L != L || lw.CS != CS || lw.NP != m->NP || !lw.item_iv.p) {
     std::vector<int> h_iv;
@@ -782,6 +789,7 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
                             &lw.slog32, &lw.vpre, &lw.vend, &lw.vgain, &lw.vtierows, &lw.vpiecemin})
       d->release();
     for (DBuf<int> *d : {&lw.ok_f, &lw.ok_b, &lw.vbad, &lw.vntie, &lw.vties}) d->release();
+    lw.B32.release();
     lw.L = L; lw.CS = CS; lw.NP = m->NP;
     lw.n_items = (int)h_iv.size();
     lw.n_groups = (lw.n_items + 63) / 64;
@@ -809,13 +817,18 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
     HIPCHK(lw.BH.alloc(rows * m->NP));
     if (!lw.MS.p) HIPCHK(lw.MS.alloc(rows));
   }
+  if (want_gain && !lw.B32.p) {
+    HIPCHK(lw.B32.alloc(rows * m->NP));
+    if (!lw.MS.p) HIPCHK(lw.MS.alloc(rows));
+    if (!lw.vgain.p) HIPCHK(lw.vgain.alloc((size_t)std::max(1, lw.n_groups) * 64));
+  }
   if (want_vit && !lw.B.p) {
     const size_t ni = (size_t)std::max(1, lw.n_groups) * 64;
     HIPCHK(lw.B.alloc(rows * m->NP));
     if (!lw.MS.p) HIPCHK(lw.MS.alloc(rows));
     HIPCHK(lw.vpre.alloc(vecs));
     HIPCHK(lw.vend.alloc(vecs));
-    HIPCHK(lw.vgain.alloc(ni));
+    if (!lw.vgain.p) HIPCHK(lw.vgain.alloc(ni));
     HIPCHK(lw.vbad.alloc(ni));
     HIPCHK(lw.vntie.alloc(ni));
     HIPCHK(lw.vties.alloc(ni * TEHMM_LANE_MAXTI));
@@ -890,10 +903,19 @@ static LaneGeom lane_geom(const LaneWork &lw) {
 
 template <int NT>
 static void launch_emis_lane(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em,
-                             bool want_log, bool want_lin, hipStream_t st) {
+                             bool want_log, bool want_lin, bool want_f32, hipStream_t st) {
   LaneWork &lw = b->lw;
   hipLaunchKernelGGL((k_emis_lane<NT>), dim3((lw.n_groups + 3) / 4), dim3(256), 0, st, iv, em, lane_geom(lw),
-                     m->N, want_log ? lw.B.p : (double *)nullptr, want_lin ? lw.BH.p : (double *)nullptr, lw.MS.p);
+                     m->N, want_log ? lw.B.p : (double *)nullptr, want_lin ? lw.BH.p : (double *)nullptr, lw.MS.p,
+                     want_f32 ? lw.B32.p : (float *)nullptr);
+}
+
+template <int NT>
+static void launch_gain_lane(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, int CS, int Wu,
+                             hipStream_t st) {
+  LaneWork &lw = b->lw;
+  hipLaunchKernelGGL((k_vit_gain_lane<NT>), dim3((lw.n_groups + 3) / 4), dim3(256), 0, st, iv, lane_geom(lw), m->N,
+                     CS, Wu, (const float *)m->ltP.p, (const float *)lw.B32.p, lw.vgain.p);
 }
 
 template <int NT>
@@ -1008,21 +1030,25 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     // fit next to the results; otherwise stay with the [T][N] speculative passes
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    const double need = (double)b->total * m->NP * 8.0 * 4.2;
+    const double need = (double)b->total * m->NP * 8.0 * 4.7;
     if (need > 0.85 * (double)free_b) LS = 0;
   }
   // The lane = item Viterbi passes are opt-in (TEHMM_LANE_VIT=1): bit-exact, but on gfx950 their quantised
   // pass is instruction-fetch bound and not yet faster than the lane = state pass.
   const char *lvs = std::getenv("TEHMM_LANE_VIT");
   const bool vlane = vspec && LS > 0 && lvs && std::atoi(lvs) != 0, flane = fspec && LS > 0;
+  // P0 (binade placement) as a packed-float lane pass over float emission rows; TEHMM_LANE_P0=0 keeps
+  // the fp64 lane = state pass
+  const char *lp0 = std::getenv("TEHMM_LANE_P0");
+  const bool glane = vspec && !vlane && LS > 0 && !(lp0 && std::atoi(lp0) == 0);
   const char *wus = std::getenv("TEHMM_LANE_WARMUP");
   const int WuF = std::min(LS, std::max(1, wus ? std::atoi(wus) : 96));       // forward / backward warm-up
   const int WuV = std::min(LS, 64);                                            // Viterbi warm-up (multiple of 32)
   VitChunks vc;
   std::vector<double> gain;
   if (vit) (void)hipEventRecord(b->ev[eV], b->sV);
-  if (vlane || flane) {
-    rc = lane_prepare(b, m, CS, LS, flane, vlane);
+  if (vlane || flane || glane) {
+    rc = lane_prepare(b, m, CS, LS, flane, vlane, glane);
     if (rc) return rc;
   }
   // Scheduling.  The speculative Viterbi passes, the emission rows, the forward / backward lane passes
@@ -1033,10 +1059,10 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   // rows, which depend on nothing, are computed up front).
   const bool defer_post = vit && postr && vspec && !vlane;
   if (postr) (void)hipEventRecord(b->ev[eP], b->sP);
-  if (vlane) {
+  if (vlane || glane) {
     // emission rows of every position, once, item-interleaved (log rows for Viterbi, linear for fwd/bwd)
     hipStream_t st = b->sV;
-#define CALL(NT_) launch_emis_lane<NT_>(b, m, iv, emg, vlane, flane, st)
+#define CALL(NT_) launch_emis_lane<NT_>(b, m, iv, emg, vlane, flane, glane, st)
     TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
     (void)hipEventRecord(b->ev[eV + 4], st);
@@ -1058,6 +1084,12 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
 #undef CALL
       gain.resize((size_t)std::max(1, lw.n_groups) * 64);
       HIPCHK(hipMemcpyAsync(gain.data(), lw.vgain.p, gain.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    } else if (glane) {
+#define CALL(NT_) launch_gain_lane<NT_>(b, m, iv, CS, WuV, st)
+      TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+      gain.resize((size_t)std::max(1, lw.n_groups) * 64);
+      HIPCHK(hipMemcpyAsync(gain.data(), lw.vgain.p, gain.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     } else {
 #define CALL(NT_) launch_vit_spec<NT_>(b, m, iv, emg, vc, false, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
@@ -1067,10 +1099,10 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     }
   }
   auto enqueue_emission = [&]() {
-    if (flane && !vlane) {
+    if (flane && !vlane && !glane) {
       // emission rows (linear domain) for the forward / backward lane passes
       hipStream_t st = b->sP;
-#define CALL(NT_) launch_emis_lane<NT_>(b, m, iv, emg, false, true, st)
+#define CALL(NT_) launch_emis_lane<NT_>(b, m, iv, emg, false, true, false, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
       (void)hipEventRecord(b->ev[eP + 4], st);
@@ -1151,12 +1183,9 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     rc = enqueue_posterior();
     if (rc) return rc;
   }
-  if (vit) {
-    hipStream_t st = b->sV;
-    if (vlane) {
-      HIPCHK(hipStreamSynchronize(st));
-      // item gains -> chunk gains -> binades; one P2 wave per (group, binade) pair
-      std::vector<double> cgain((size_t)std::max(1, sw.n_chunks), 0.0);
+  // item gains of a lane P0 pass -> chunk gains (chunks the lanes did not run: see below)
+  auto chunk_gains = [&](std::vector<double> &cgain) {
+      cgain.assign((size_t)std::max(1, sw.n_chunks), 0.0);
       const int SUB = CS / LS;
       for (int c = 0; c < sw.n_chunks; ++c) {
         const int id = sw.h_iv[(size_t)c];
@@ -1181,6 +1210,14 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
             cgain[(size_t)c] = (c == sw.h_first[i] || clen < CS) ? mean * (double)clen / (double)CS : std::nan("");
           }
       }
+  };
+  if (vit) {
+    hipStream_t st = b->sV;
+    if (vlane) {
+      HIPCHK(hipStreamSynchronize(st));
+      // item gains -> chunk gains -> binades; one P2 wave per (group, binade) pair
+      std::vector<double> cgain;
+      chunk_gains(cgain);
       std::vector<int> he;
       spec_assign_binades(b, cgain, he);
       // quantised tables of the binades in use
@@ -1245,7 +1282,15 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     } else if (vspec) {
       HIPCHK(hipStreamSynchronize(st));
       std::vector<int> he;
-      spec_assign_binades(b, gain, he);
+      if (glane) {
+        std::vector<double> cgain;
+        chunk_gains(cgain);
+        spec_assign_binades(b, cgain, he);
+        HIPCHK(hipMemcpyAsync(sw.gain.p, cgain.data(), cgain.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));          // cgain is a local
+      } else {
+        spec_assign_binades(b, gain, he);
+      }
       HIPCHK(hipMemcpyAsync(sw.e.p, he.data(), he.size() * sizeof(int), hipMemcpyHostToDevice, st));
       HIPCHK(hipMemsetAsync(sw.ok.p, 0, he.size() * sizeof(int), st));
       HIPCHK(hipMemsetAsync(sw.stats.p, 0, 2 * sizeof(int), st));
@@ -1278,7 +1323,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
                          b->n_chunks, b->d_chunk_iv.p, b->d_chunk0.p, b->TBW, b->tb.p, b->bstate.p,
                          b->paths.p);
     (void)hipEventRecord(b->ev[eV + 2], st);
-    if (vlane) {
+    if (vlane || glane) {
       b->tnames.push_back("emission_rows");
       b->tpairs.push_back({eV, eV + 4});
       b->tnames.push_back("viterbi_speculate");
@@ -1299,7 +1344,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   }
   if (postr) {
     if (flane) {
-      if (!vlane) {
+      if (!vlane && !glane) {
         b->tnames.push_back("emission_rows");
         b->tpairs.push_back({eP, eP + 4});
       }

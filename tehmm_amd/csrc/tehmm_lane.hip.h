@@ -34,13 +34,13 @@ typedef __attribute__((address_space(4))) const double const_f64;
 
 // ------------------------------------------------------------------------------------------
 // Emission rows of every position, item-interleaved.  B = log rows (the reference's operation
-// order, _emission.pyx:65-72), BH = exp(B - rowmax), MS = rowmax.  A row no state can emit is
+// order, _emission.pyx:65-72), B32 = the same rounded to float, BH = exp(B - rowmax), MS = rowmax.  A row no state can emit is
 // written as NaN: it poisons the lane passes, their links fail and the exact chain -- which owns the
 // reference's semantics for such rows (leading-rows quirk, dead lattices) -- walks through it.
 // ------------------------------------------------------------------------------------------
 template <int NT>
 __global__ __launch_bounds__(256) void k_emis_lane(IntervalTab iv, EmisTab em, LaneGeom lg, int N,
-                                                   double *B, double *BH, double *MS) {
+                                                   double *B, double *BH, double *MS, float *B32) {
   const int lane = threadIdx.x & 63;
   const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (g >= lg.n_groups) return;
@@ -66,6 +66,10 @@ __global__ __launch_bounds__(256) void k_emis_lane(IntervalTab iv, EmisTab em, L
       if (B) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) B[o + ((int64_t)j << 6)] = good ? x[j] : qnan;
+      }
+      if (B32) {                        // log rows rounded to float: enough for the binade-placement pass
+#pragma unroll
+        for (int j = 0; j < NT; ++j) B32[o + ((int64_t)j << 6)] = good ? (float)x[j] : (float)qnan;
       }
       if (BH) {
 #pragma unroll
@@ -699,6 +703,75 @@ __global__ __launch_bounds__(256) void k_vit_stitch(IntervalTab iv, LaneGeom lg,
     vc.ntie[c] = nT;
     vc.ok[c] = (okc && nT <= TEHMM_SPEC_MAXT) ? 1 : 0;
   }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// P0 of the exact chunk-parallel Viterbi as a lane = item pass in PACKED FLOAT arithmetic.  P0 only
+// has to place every chunk in its fp64 binade (the exact kernels re-verify whatever they use), so the
+// score gained over an item needs ~1e-4 relative accuracy: float max-plus over 512 + 64 positions
+// from a zero start is far inside that.  Two outputs share a register pair: v_pk_add_f32 adds the
+// broadcast W[f] to a scalar pair of table entries, v_max3_f32 folds two candidates per half.
+// gain[item] = max W_end - max W_pre (the converged vector's decrease over the official range).
+// tabf: [o / 2][f][o % 2] floats (NT * NT), pads -inf.
+// ------------------------------------------------------------------------------------------
+typedef float lane_f2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(4))) const lane_f2 const_f2;
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_vit_gain_lane(IntervalTab iv, LaneGeom lg, int N, int CS, int Wu,
+                                                       const float *__restrict__ tabf,
+                                                       const float *__restrict__ B32, double *gain) {
+  const int lane = threadIdx.x & 63;
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= lg.n_groups) return;
+  const int L = lg.L;
+  const int64_t item = (int64_t)g * 64 + lane;
+  const bool valid = item < lg.n_items;
+  const int id = valid ? lg.item_iv[item] : 0;
+  const int64_t t0 = valid ? lg.item_t0[item] : 0;
+  const int64_t T = iv.len[id];
+  const int64_t ct0 = (t0 / CS) * CS;
+  const bool run = valid && ct0 > 0 && ct0 + CS <= T;
+  if (!__any(run)) return;
+  const int64_t nb = run ? item - 1 : item;
+  lane_f2 W[NT / 2];
+#pragma unroll
+  for (int j = 0; j < NT / 2; ++j)
+    W[j] = (lane_f2){2 * j < N ? 0.f : -INFINITY, 2 * j + 1 < N ? 0.f : -INFINITY};
+  bool bad = false;
+  auto vec_max = [&]() {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NT / 2; ++j) mx = fmaxf(mx, fmaxf(W[j].x, W[j].y));
+    return mx;
+  };
+  float g0 = 0.f;
+  for (int s = -Wu; s < L; ++s) {
+    if (s == 0) g0 = vec_max();
+    const float *bp = B32 + (s < 0 ? lane_row(lg, NT, nb, L + s) : lane_row(lg, NT, item, s));
+    float b[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b[j] = bp[(int64_t)j << 6];
+    bad = bad | (b[0] != b[0]);
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    const_f2 *tp = (const_f2 *)(size_t)tabf + z;
+    lane_f2 x[NT / 2];
+#pragma unroll
+    for (int op = 0; op < NT / 2; ++op) {
+      lane_f2 acc = (lane_f2){W[0].x, W[0].x} + tp[op * NT];
+#pragma unroll
+      for (int f = 1; f < NT; ++f) {
+        const float wf = (f & 1) ? W[f >> 1].y : W[f >> 1].x;
+        acc = __builtin_elementwise_max(acc, (lane_f2){wf, wf} + tp[op * NT + f]);
+      }
+      x[op] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j < NT / 2; ++j) W[j] = x[j] + (lane_f2){b[2 * j], b[2 * j + 1]};
+  }
+  if (run) gain[item] = bad ? __longlong_as_double(0x7ff8000000000000LL) : (double)vec_max() - (double)g0;
 }
 
 }  // namespace tehmm
