@@ -1316,7 +1316,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     if (b->n_chunks > 0)
       hipLaunchKernelGGL(k_tb_compose, dim3(b->n_chunks), dim3(64), 0, st, iv, b->d_chunk_iv.p,
                          b->d_chunk0.p, m->N, m->NP, b->TBW, b->tb.p, b->G.p);
-    hipLaunchKernelGGL(k_tb_scan, dim3(grid_for(b->n, 64)), dim3(64), 0, st, iv, b->d_chunk0.p, m->NP,
+    hipLaunchKernelGGL(k_tb_scan, dim3(std::max(1, b->n)), dim3(64), 0, st, iv, b->d_chunk0.p, m->NP,
                        b->G.p, b->last_state.p, b->bstate.p, b->paths.p);
     if (b->n_chunks > 0)
       hipLaunchKernelGGL(k_tb_fill, dim3(grid_for(b->n_chunks, 64, 1 << 30)), dim3(64), 0, st, iv,

@@ -486,6 +486,7 @@ __device__ __forceinline__ int tb_get(const uint8_t *tb, int TBW, int64_t gpos, 
 __global__ __launch_bounds__(64) void k_tb_compose(IntervalTab iv, const int *chunk_iv,
                                                    const int64_t *chunk0, int N, int NP, int TBW,
                                                    const uint8_t *tb, uint8_t *G) {
+  __builtin_amdgcn_s_setprio(3);      // latency kernel: issue ahead of co-resident throughput waves
   const int c = blockIdx.x;
   const int id = chunk_iv[c];
   const int64_t T = iv.len[id], p0 = iv.pos0[id];
@@ -499,23 +500,48 @@ __global__ __launch_bounds__(64) void k_tb_compose(IntervalTab iv, const int *ch
   }
 }
 // scan: sequential over the chunks of one interval (T/C dependent byte lookups)
-__global__ void k_tb_scan(IntervalTab iv, const int64_t *chunk0, int NP, const uint8_t *G,
-                          const int *last_state, uint8_t *bstate, int64_t *paths) {
-  int id = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per interval.  The chain over the interval's chunks (state at the chunk end -> state at its
+// start) is a dependent walk; 64 chunk maps at a time are fetched cooperatively into LDS so that the walk
+// itself only touches LDS (it used to pay one global-memory latency per chunk, ~16 ms next to an
+// HBM-bound kernel for a 2 Mb interval).
+__global__ __launch_bounds__(64) void k_tb_scan(IntervalTab iv, const int64_t *chunk0, int NP, const uint8_t *G,
+                                                const int *last_state, uint8_t *bstate, int64_t *paths) {
+  __builtin_amdgcn_s_setprio(3);      // latency kernel: issue ahead of co-resident throughput waves
+  __shared__ uint8_t rows[64 * 136];   // NP <= 132
+  __shared__ uint8_t bst[64];
+  const int id = blockIdx.x;
+  const int lane = threadIdx.x;
   if (id >= iv.n) return;
-  int64_t T = iv.len[id];
+  const int64_t T = iv.len[id];
   if (T <= 0) return;
   int s = last_state[id];
-  int64_t c0 = chunk0[id], nc = chunk0[id + 1] - c0;
-  if (nc == 0) { paths[iv.out0[id]] = s; return; }
-  for (int64_t c = nc - 1; c >= 0; --c) {
-    bstate[c0 + c] = (uint8_t)s;
-    s = G[(c0 + c) * NP + s];
+  const int64_t c0 = chunk0[id], nc = chunk0[id + 1] - c0;
+  if (nc == 0) {
+    if (lane == 0) paths[iv.out0[id]] = s;
+    return;
+  }
+  for (int64_t hi = nc; hi > 0; hi -= 64) {
+    const int64_t lo = hi > 64 ? hi - 64 : 0;
+    const int n = (int)(hi - lo);
+    const uint8_t *src = G + (c0 + lo) * NP;
+    for (int i = lane; i < n * NP; i += 64) rows[i] = src[i];
+    __syncthreads();
+    if (lane == 0) {
+      for (int c = n - 1; c >= 0; --c) {
+        bst[c] = (uint8_t)s;
+        s = rows[c * NP + s];
+      }
+    }
+    __syncthreads();
+    s = __shfl(s, 0);
+    if (lane < n) bstate[c0 + lo + lane] = bst[lane];
+    __syncthreads();
   }
 }
 // fill: one thread per chunk walks its pointers and writes the int64 path
 __global__ void k_tb_fill(IntervalTab iv, int n_chunks, const int *chunk_iv, const int64_t *chunk0,
                           int TBW, const uint8_t *tb, const uint8_t *bstate, int64_t *paths) {
+  __builtin_amdgcn_s_setprio(3);      // latency kernel: issue ahead of co-resident throughput waves
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_chunks) return;
   const int id = chunk_iv[c];
