@@ -124,7 +124,8 @@ struct LaneWork {
   std::vector<int> h_iv;
   std::vector<int64_t> h_t0, h_first;
   int64_t h_first_item(int id) const { return h_first[(size_t)id]; }
-  DBuf<int> item_iv, ok_f, ok_b;
+  DBuf<int> item_iv, ok_f, ok_b, link_f, link_b, runend_f, runstart_b;
+  DBuf<double> glog_f, cpre_f;
   DBuf<int64_t> item_t0, ifirst;
   DBuf<double> B, BH, MS, AL, BE, pre_f, end_f, pre_b, end_b, slog32;
   // Viterbi lane passes
@@ -788,7 +789,11 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
     for (DBuf<double> *d : {&lw.B, &lw.BH, &lw.MS, &lw.AL, &lw.BE, &lw.pre_f, &lw.end_f, &lw.pre_b, &lw.end_b,
                             &lw.slog32, &lw.vpre, &lw.vend, &lw.vgain, &lw.vtierows, &lw.vpiecemin})
       d->release();
-    for (DBuf<int> *d : {&lw.ok_f, &lw.ok_b, &lw.vbad, &lw.vntie, &lw.vties}) d->release();
+    for (DBuf<int> *d : {&lw.ok_f, &lw.ok_b, &lw.vbad, &lw.vntie, &lw.vties, &lw.link_f, &lw.link_b, &lw.runend_f,
+                         &lw.runstart_b})
+      d->release();
+    lw.glog_f.release();
+    lw.cpre_f.release();
     lw.B32.release();
     lw.L = L; lw.CS = CS; lw.NP = m->NP;
     lw.n_items = (int)h_iv.size();
@@ -812,6 +817,10 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
     HIPCHK(lw.slog32.alloc((size_t)std::max(1, lw.n_groups) * 64 * (L / 32)));
     HIPCHK(lw.ok_f.alloc((size_t)std::max(1, b->sw.n_chunks)));
     HIPCHK(lw.ok_b.alloc((size_t)std::max(1, b->sw.n_chunks)));
+    for (DBuf<int> *d : {&lw.link_f, &lw.link_b, &lw.runend_f, &lw.runstart_b})
+      HIPCHK(d->alloc((size_t)std::max(1, b->sw.n_chunks)));
+    HIPCHK(lw.glog_f.alloc((size_t)std::max(1, b->sw.n_chunks)));
+    HIPCHK(lw.cpre_f.alloc((size_t)std::max(1, b->sw.n_chunks)));
   }
   if (want_fb && !lw.BH.p) {
     HIPCHK(lw.BH.alloc(rows * m->NP));
@@ -930,6 +939,9 @@ static void launch_fb_lane(tehmm_batch *b, const tehmm_model *m, const IntervalT
                      lw.MS.p, lw.BE.p, lw.pre_b.p, lw.end_b.p, (double *)nullptr);
   hipLaunchKernelGGL((k_fb_stitch<NT>), dim3((fc.n + 3) / 4), dim3(256), 0, st, iv, lg, fc, m->N, lw.pre_f.p,
                      lw.end_f.p, lw.slog32.p, lw.pre_b.p, lw.end_b.p, lw.ok_f.p, lw.ok_b.p);
+  const char *er = std::getenv("TEHMM_FB_RUNS");
+  hipLaunchKernelGGL(k_fb_runs, dim3((b->n + 63) / 64), dim3(64), 0, st, iv, fc, (const int *)lw.ok_f.p,
+                     (const int *)lw.ok_b.p, (er && std::atoi(er) == 0) ? 0 : 1);
 }
 
 template <int NT>
@@ -1042,7 +1054,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   const char *lp0 = std::getenv("TEHMM_LANE_P0");
   const bool glane = vspec && !vlane && LS > 0 && !(lp0 && std::atoi(lp0) == 0);
   const char *wus = std::getenv("TEHMM_LANE_WARMUP");
-  const int WuF = std::min(LS, std::max(1, wus ? std::atoi(wus) : 96));       // forward / backward warm-up
+  const int WuF = std::min(LS, std::max(1, wus ? std::atoi(wus) : 64));       // forward / backward warm-up
   const int WuV = std::min(LS, 64);                                            // Viterbi warm-up (multiple of 32)
   VitChunks vc;
   std::vector<double> gain;
@@ -1114,9 +1126,11 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     if (flane) {
       // lane = item passes (forward, backward, links), then the two sequential chains on the
       // item-interleaved rows, then the transposing combine
-      FbChunks fc;
+      FbChunks fc{};
       fc.iv = sw.iv.p; fc.t0 = sw.t0.p; fc.first = sw.first.p; fc.n = sw.n_chunks; fc.CS = CS;
       fc.scale = sw.scale.p; fc.wstart = sw.wstart.p;
+      fc.link_f = lw.link_f.p; fc.glog_f = lw.glog_f.p; fc.link_b = lw.link_b.p; fc.runend_f = lw.runend_f.p;
+      fc.pre_f = lw.cpre_f.p; fc.runstart_b = lw.runstart_b.p;
       (void)hipMemsetAsync(b->dead.p, 0, (size_t)(b->n + 1) * sizeof(int), st);
       (void)hipMemsetAsync(sw.stats.p + 2, 0, 4 * sizeof(int), st);
 #define CALL(NT_) launch_fb_lane<NT_>(b, m, iv, fc, WuF, st)
@@ -1140,7 +1154,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       // sequential chains (forward on this stream, backward on its own) with verified jumps
       rc = ensure_beta(b, m);
       if (rc) return rc;
-      FbChunks fc;
+      FbChunks fc{};
       fc.iv = sw.iv.p; fc.t0 = sw.t0.p; fc.first = sw.first.p; fc.n = sw.n_chunks; fc.CS = CS;
       fc.scale = sw.scale.p; fc.wstart = sw.wstart.p;
       (void)hipMemsetAsync(b->dead.p, 0, (size_t)(b->n + 1) * sizeof(int), st);
@@ -1371,6 +1385,19 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, b->ev[pr.first], b->ev[pr.second]);
     b->tms.push_back((double)ms);
+  }
+  if (flane && std::getenv("TEHMM_SPEC_DEBUG")) {
+    const size_t nc = (size_t)sw.n_chunks;
+    std::vector<int> re(nc), rb(nc), lf(nc), lb(nc), of(nc), ob(nc);
+    HIPCHK(hipMemcpy(re.data(), lw.runend_f.p, nc * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rb.data(), lw.runstart_b.p, nc * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(lf.data(), lw.link_f.p, nc * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(lb.data(), lw.link_b.p, nc * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(of.data(), lw.ok_f.p, nc * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ob.data(), lw.ok_b.p, nc * 4, hipMemcpyDeviceToHost));
+    for (size_t c = 0; c < nc && c < 48; ++c)
+      std::fprintf(stderr, "[fb runs] c %zu ok_f %d link_f %d runend_f %d | ok_b %d link_b %d runstart_b %d\n", c, of[c],
+                   lf[c], re[c], ob[c], lb[c], rb[c]);
   }
   if (fspec) {
     int st[4] = {0, 0, 0, 0};

@@ -292,6 +292,23 @@ __global__ __launch_bounds__(256) void k_fb_stitch(IntervalTab iv, LaneGeom lg, 
       }
       for (int m = lane; m < R; m += 64) fc.scale[(int64_t)c * (fc.CS / 32) + k * R + m] = slog32[item * R + m] + off;
     }
+    // link to the previous chunk (if the lanes ran it): its last item's end vector against this chunk's
+    // first pre vector; glog = log-scale gained over this chunk, expressed in the previous chunk's frame
+    int lf = 0;
+    double gl = 0.0;
+    if (okf && c - 1 != fc.first[id]) {
+      double rho;
+      const double d = proj_dist(at(pre_f, item0), at(end_f, item0 - 1), live, rho);
+      lf = d <= TEHMM_FB_TOL ? 1 : 0;
+      gl = off + slog32[(item0 + SUB - 1) * R + R - 1] - log(rho);
+    }
+    if (lane == 0) {
+      fc.link_f[c] = lf;
+      fc.glog_f[c] = gl;
+    }
+  } else if (lane == 0) {
+    fc.link_f[c] = 0;
+    fc.glog_f[c] = 0.0;
   }
   bool okb = full && ct0 + fc.CS < T;
   if (okb) {
@@ -301,10 +318,48 @@ __global__ __launch_bounds__(256) void k_fb_stitch(IntervalTab iv, LaneGeom lg, 
       okb = okb && d <= TEHMM_FB_TOL;
     }
     if (lane < NT) fc.wstart[(int64_t)c * NT + lane] = at(end_b, item0);
+    // link to the next chunk (if the lanes ran it for the backward pass)
+    int lb = 0;
+    const int64_t nt0 = ct0 + fc.CS;
+    if (okb && nt0 + fc.CS < T) {
+      double rho;
+      const double d = proj_dist(at(pre_b, item0 + SUB - 1), at(end_b, item0 + SUB), live, rho);
+      lb = d <= TEHMM_FB_TOL ? 1 : 0;
+    }
+    if (lane == 0) fc.link_b[c] = lb;
+  } else if (lane == 0) {
+    fc.link_b[c] = 0;
   }
   if (lane == 0) {
     ok_f[c] = okf ? 1 : 0;
     ok_b[c] = okb ? 1 : 0;
+  }
+}
+
+// Runs of linked chunks, one thread per interval: a verified jump of the fix-up chain carries on over
+// every following chunk whose links hold (forward: towards the interval end; backward: towards its
+// start), so a long interval costs its first chunk plus one verification, not one per chunk.
+__global__ void k_fb_runs(IntervalTab iv, FbChunks fc, const int *ok_f, const int *ok_b, int extend) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= iv.n) return;
+  const int64_t c0 = fc.first[id], c1 = fc.first[id + 1];
+  double acc = 0.0;
+  for (int64_t c = c0; c < c1; ++c) {
+    acc += fc.link_f[c] ? fc.glog_f[c] : 0.0;
+    fc.pre_f[c] = acc;
+  }
+  int run = (int)(c1 - 1);
+  for (int64_t c = c1 - 1; c >= c0; --c) {
+    // chunk c + 1 continues chunk c iff its own links hold and its first item continues c's last one
+    const bool cont = extend != 0 && c + 1 < c1 && ok_f[c + 1] != 0 && fc.link_f[c + 1] != 0;
+    if (!cont) run = (int)c;
+    fc.runend_f[c] = run;
+  }
+  run = (int)c0;
+  for (int64_t c = c0; c < c1; ++c) {
+    const bool cont = extend != 0 && c > c0 && ok_b[c - 1] != 0 && fc.link_b[c - 1] != 0;
+    if (!cont) run = (int)c;
+    fc.runstart_b[c] = run;
   }
 }
 

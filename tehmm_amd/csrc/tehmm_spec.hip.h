@@ -460,6 +460,13 @@ struct FbChunks {
   int n, CS;
   double *scale;          // forward spec: [chunk][CS/32] cumulative log-scale at positions t0+32k+31
   double *wstart;         // backward spec: [chunk][NT] w row (bh' * beta) at the chunk's first position
+  // lane passes only: runs of consecutive chunks whose item links all hold (k_fb_stitch / k_fb_runs)
+  int *link_f;            // [chunk] 1 = the chunk's first item continues the previous chunk's last item
+  double *glog_f;         // [chunk] log-scale gained over the chunk, in the frame of the previous chunk
+  int *link_b;            // [chunk] 1 = the chunk's last item continues the next chunk's first item
+  int *runend_f;          // [chunk] last chunk of the forward run that contains the chunk
+  double *pre_f;          // [chunk] prefix sums of glog_f along the interval
+  int *runstart_b;        // [chunk] first chunk of the backward run that contains the chunk
 };
 #define TEHMM_FB_TOL 1e-10
 
@@ -658,6 +665,7 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
     for (int it = 0;; ++it) {
       const int64_t cur = seqpos[it & 3];
       if (done(cur)) break;
+      if (it > (1 << 22)) { if (stats && lane == 0) atomicAdd(&stats[6], 1); break; }   // never expected: the grid must drain
       ++n_block;
       const int64_t lo = block_lo(cur);
       const int np = block_np(cur);
@@ -674,7 +682,9 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
       const int64_t rstride = LANE ? (int64_t)NT << 6 : (int64_t)N;
       const int pg = DIR == 0 ? 31 : 32;                        // check step inside the block
       const int64_t tg = DIR == 0 ? lo + pg : cur - 1 - pg;     // its position
-      const int64_t target = DIR == 0 ? ct0 + fc.CS : ct0;      // key of the block after a jump
+      // LANE: a jump runs to the end of the whole run of linked chunks, not just of this chunk
+      const int64_t cj = !LANE ? c : (DIR == 0 ? cfirst + (fc.runend_f[c] - cfirst) : cfirst + (fc.runstart_b[c] - cfirst));
+      const int64_t target = DIR == 0 ? fc.t0[cj] + fc.CS : fc.t0[cj];      // key of the block after a jump
       double srow = 0.0;
       if (spec) srow = live ? brow[(tg - lo) * rstride] : 0.0;  // speculative row, before overwriting
       else if (lane == 0) {
@@ -742,9 +752,10 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
           v = live ? *rowp(tl) : 0.0;
           const double *sc = fc.scale + c * (fc.CS / 32);
           Mcum = Sg + log(rho) + (sc[fc.CS / 32 - 1] - sc[(tg - ct0) / 32]);
+          if (LANE) Mcum += fc.pre_f[cj] - fc.pre_f[c];
           Ecum = 0.0;
         } else {
-          v = live ? fc.wstart[c * NT + jl] : 0.0;
+          v = live ? fc.wstart[cj * NT + jl] : 0.0;
         }
       }
       __syncthreads();
@@ -758,6 +769,7 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
     for (int it = 0;; ++it) {
       const int64_t cur = seqpos[it & 3];
       if (done(cur)) break;
+      if (it > (1 << 22)) break;
       int spins = 0;
       while (*gen < it + 1) {
         __builtin_amdgcn_s_sleep(8);
