@@ -914,7 +914,9 @@ template <int NT>
 static void launch_emis_lane(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em,
                              bool want_log, bool want_lin, bool want_f32, hipStream_t st) {
   LaneWork &lw = b->lw;
-  hipLaunchKernelGGL((k_emis_lane<NT>), dim3((lw.n_groups + 3) / 4), dim3(256), 0, st, iv, em, lane_geom(lw),
+  const size_t lds = (size_t)em.lds_rows * NT * sizeof(double);
+  allow_lds(k_emis_lane<NT>, lds);
+  hipLaunchKernelGGL((k_emis_lane<NT>), dim3((lw.n_groups + 3) / 4), dim3(256), lds, st, iv, em, lane_geom(lw),
                      m->N, want_log ? lw.B.p : (double *)nullptr, want_lin ? lw.BH.p : (double *)nullptr, lw.MS.p,
                      want_f32 ? lw.B32.p : (float *)nullptr);
 }
@@ -933,10 +935,31 @@ static void launch_fb_lane(tehmm_batch *b, const tehmm_model *m, const IntervalT
   LaneWork &lw = b->lw;
   const LaneGeom lg = lane_geom(lw);
   const dim3 grid((lw.n_groups + 3) / 4);
-  hipLaunchKernelGGL((k_fb_lane<NT, 0>), grid, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->AG.p, lw.BH.p,
-                     lw.MS.p, lw.AL.p, lw.pre_f.p, lw.end_f.p, lw.slog32.p);
-  hipLaunchKernelGGL((k_fb_lane<NT, 1>), grid, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->ATG.p, lw.BH.p,
-                     lw.MS.p, lw.BE.p, lw.pre_b.p, lw.end_b.p, (double *)nullptr);
+  // TEHMM_LANE_MFMA: 0 = both passes in the VALU form (default), 1 = both on the fp64 matrix cores,
+  // 2 = forward on the matrix cores and backward in the VALU form, concurrently on two streams
+  const char *mfs = std::getenv("TEHMM_LANE_MFMA");
+  const int mf = mfs ? std::atoi(mfs) : 0;
+  const dim3 gridm((unsigned)lw.n_groups);           // 4 tiles of 16 items per 256-thread block = one group
+  if (mf == 2) {
+    (void)hipEventRecord(b->evX[0], st);
+    (void)hipStreamWaitEvent(b->sB, b->evX[0], 0);
+    hipLaunchKernelGGL((k_fb_mfma<NT, 0>), gridm, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->A.p, lw.BH.p,
+                       lw.MS.p, lw.AL.p, lw.pre_f.p, lw.end_f.p, lw.slog32.p);
+    hipLaunchKernelGGL((k_fb_lane<NT, 1>), grid, dim3(256), 0, b->sB, iv, lg, m->N, fc.CS, Wu, m->ATG.p, lw.BH.p,
+                       lw.MS.p, lw.BE.p, lw.pre_b.p, lw.end_b.p, (double *)nullptr);
+    (void)hipEventRecord(b->evX[1], b->sB);
+    (void)hipStreamWaitEvent(st, b->evX[1], 0);
+  } else if (mf == 1) {
+    hipLaunchKernelGGL((k_fb_mfma<NT, 0>), gridm, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->A.p, lw.BH.p,
+                       lw.MS.p, lw.AL.p, lw.pre_f.p, lw.end_f.p, lw.slog32.p);
+    hipLaunchKernelGGL((k_fb_mfma<NT, 1>), gridm, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->A.p, lw.BH.p,
+                       lw.MS.p, lw.BE.p, lw.pre_b.p, lw.end_b.p, (double *)nullptr);
+  } else {
+    hipLaunchKernelGGL((k_fb_lane<NT, 0>), grid, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->AG.p, lw.BH.p,
+                       lw.MS.p, lw.AL.p, lw.pre_f.p, lw.end_f.p, lw.slog32.p);
+    hipLaunchKernelGGL((k_fb_lane<NT, 1>), grid, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->ATG.p, lw.BH.p,
+                       lw.MS.p, lw.BE.p, lw.pre_b.p, lw.end_b.p, (double *)nullptr);
+  }
   hipLaunchKernelGGL((k_fb_stitch<NT>), dim3((fc.n + 3) / 4), dim3(256), 0, st, iv, lg, fc, m->N, lw.pre_f.p,
                      lw.end_f.p, lw.slog32.p, lw.pre_b.p, lw.end_b.p, lw.ok_f.p, lw.ok_b.p);
   const char *er = std::getenv("TEHMM_FB_RUNS");
@@ -1074,7 +1097,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   if (vlane || glane) {
     // emission rows of every position, once, item-interleaved (log rows for Viterbi, linear for fwd/bwd)
     hipStream_t st = b->sV;
-#define CALL(NT_) launch_emis_lane<NT_>(b, m, iv, emg, vlane, flane, glane, st)
+#define CALL(NT_) launch_emis_lane<NT_>(b, m, iv, em, vlane, flane, glane, st)
     TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
     (void)hipEventRecord(b->ev[eV + 4], st);
@@ -1114,7 +1137,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     if (flane && !vlane && !glane) {
       // emission rows (linear domain) for the forward / backward lane passes
       hipStream_t st = b->sP;
-#define CALL(NT_) launch_emis_lane<NT_>(b, m, iv, emg, false, true, false, st)
+#define CALL(NT_) launch_emis_lane<NT_>(b, m, iv, em, false, true, false, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
       (void)hipEventRecord(b->ev[eP + 4], st);

@@ -41,6 +41,9 @@ typedef __attribute__((address_space(4))) const double const_f64;
 template <int NT>
 __global__ __launch_bounds__(256) void k_emis_lane(IntervalTab iv, EmisTab em, LaneGeom lg, int N,
                                                    double *B, double *BH, double *MS, float *B32) {
+  extern __shared__ double emis_ltab[];           // the small tracks' table rows (em.lds_rows of them)
+  stage_emis_table(em, emis_ltab, NT);
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (g >= lg.n_groups) return;
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256) void k_emis_lane(IntervalTab iv, EmisTab em, L
     const bool act = s < len;
     const int64_t gpos = p0 + t0 + (act ? s : 0);
     double x[NT];
-    emis_rows<NT>(em, nullptr, gpos, x);
+    emis_rows<NT>(em, emis_ltab, gpos, x);
     double m = x[0];
 #pragma unroll
     for (int j = 1; j < NT; ++j) m = fmax(m, j < N ? x[j] : -INFINITY);
@@ -251,6 +254,137 @@ void k_fb_lane(IntervalTab iv, LaneGeom lg, int N, int CS, int Wu, const double 
 #pragma unroll
       for (int j = 0; j < NT; ++j) end[po + ((int64_t)j << 6)] = v[j];
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward / backward lane pass on the fp64 MATRIX cores (same interface and results as k_fb_lane).
+// The VALU form is instruction-fetch bound (one 4..8-byte instruction per 64 FMAs); one
+// v_mfma_f64_16x16x4_f64 carries 1 024 FMAs and needs no scalar operand stream.  Per step and tile of
+// 16 items the product is computed TRANSPOSED,
+//     D'[state j][item i] = sum_k  T[j][k] * V[k][i],     T[j][k] = A[k][j] (forward) or A[j][k] (backward),
+// because then the accumulator layout of the instruction (lane l, register r: row (l >> 4) + 4 r of a
+// 16-row tile, column l & 15) IS the B-operand layout of the next step (lane l: k = 4 s + (l >> 4),
+// column l & 15) with s = r + 4 * (row tile): the recurrence never leaves the registers and needs no
+// cross-lane movement.  Lane l owns item (l & 15) of its tile and the states (l >> 4) + 4 s; the
+// table lives in NT/4 * ceil(NT/16) constant fragments (27 doubles per lane for NT = 36).
+// ------------------------------------------------------------------------------------------
+typedef double lane_d4 __attribute__((ext_vector_type(4)));
+
+template <int NT, int DIR>
+__global__ __launch_bounds__(256) void k_fb_mfma(IntervalTab iv, LaneGeom lg, int N, int CS, int Wu,
+                                                 const double *__restrict__ tab /* A, [NT][NT] row-major */,
+                                                 const double *__restrict__ BH, const double *__restrict__ MS,
+                                                 double *rows, double *pre, double *end, double *slog32) {
+  constexpr int KS = NT / 4;             // k-steps of 4 states
+  constexpr int RT = (NT + 15) / 16;     // row tiles of 16 states
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= lg.n_groups * 4) return;
+  const int L = lg.L;
+  const int kq = lane >> 4;
+  const int64_t item = (int64_t)tile * 16 + (lane & 15);
+  const bool valid = item < lg.n_items;
+  const int id = valid ? lg.item_iv[item] : 0;
+  const int64_t t0 = valid ? lg.item_t0[item] : 0;
+  const int64_t T = iv.len[id];
+  const int64_t ct0 = (t0 / CS) * CS;
+  const bool run = valid && ct0 + CS <= T && (DIR == 0 ? ct0 > 0 : ct0 + CS < T);
+  if (!__any(run)) return;
+  const int64_t nb = run ? (DIR == 0 ? item - 1 : item + 1) : item;
+  const int wu = !run ? 0 : (DIR == 0 ? Wu : (int)min((int64_t)Wu, T - (t0 + L)));
+  // table fragments: A-operand lane map = T[16 rt + (l & 15)][4 s + (l >> 4)]
+  double tf[RT][KS];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int j = 16 * rt + (lane & 15), k = 4 * s + kq;
+      tf[rt][s] = (j < NT) ? (DIR == 0 ? tab[k * NT + j] : tab[j * NT + k]) : 0.0;
+    }
+  }
+  // this lane's states: kq + 4 s
+  double v[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) v[s] = (DIR == 0 && kq + 4 * s < N) ? 1.0 / (double)N : 0.0;
+  double slog = 0.0;
+  const int64_t soff = (int64_t)kq << 6;          // state kq of a row; further states are 4 * 64 doubles apart
+
+  auto product = [&](double (&out)[KS]) {
+    lane_d4 acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = (lane_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(tf[rt][s], v[s], acc[rt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) out[s] = acc[s >> 2][s & 3];
+  };
+  auto item_sum = [&](const double (&a)[KS]) {        // over the item's states: in-lane, then its 4 lanes
+    double t = 0.0;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) t += a[s];
+    t += __shfl_xor(t, 16);
+    t += __shfl_xor(t, 32);
+    return t;
+  };
+  auto vec_out = [&](double *dst) {
+    const int64_t po = ((((item >> 6) * NT) + kq) << 6) + (item & 63);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) dst[po + ((int64_t)(4 * s) << 6)] = v[s];
+  };
+
+  if (DIR == 0) {
+    for (int s = -Wu; s < L; ++s) {
+      if (s == 0) {
+        if (run) vec_out(pre);
+        slog = 0.0;
+      }
+      const int64_t o = (s < 0 ? lane_row(lg, NT, nb, L + s) : lane_row(lg, NT, item, s)) + soff;
+      double bh[KS];
+#pragma unroll
+      for (int q = 0; q < KS; ++q) bh[q] = BH[o + ((int64_t)(4 * q) << 6)];
+      const double ms = s < 0 ? 0.0 : MS[(((item >> 6) * L + s) << 6) + (item & 63)];
+      double acc[KS];
+      product(acc);
+#pragma unroll
+      for (int q = 0; q < KS; ++q) acc[q] *= bh[q];
+      const double tot = item_sum(acc);
+      const int e = ((__double2hiint(tot) >> 20) & 0x7ff) - 1022;
+#pragma unroll
+      for (int q = 0; q < KS; ++q) v[q] = ldexp(acc[q], -e);
+      slog += (double)e * 0.6931471805599453 + ms;
+      if (s >= 0 && run) {
+#pragma unroll
+        for (int q = 0; q < KS; ++q) rows[o + ((int64_t)(4 * q) << 6)] = v[q];
+        if ((s & 31) == 31 && kq == 0) slog32[item * (L / 32) + (s >> 5)] = slog;
+      }
+    }
+    if (run) vec_out(end);
+  } else {
+    for (int s = L + Wu - 1; s >= 0; --s) {
+      const int top = L + wu - 1;                        // first (highest) warm-up position of this item
+      if (s == L - 1 && run) vec_out(pre);               // v = w_{t0+L} after the warm-up
+      const int sc = s >= L ? max(min(s, top) - L, 0) : s;
+      const int64_t o = (s >= L ? lane_row(lg, NT, nb, sc) : lane_row(lg, NT, item, sc)) + soff;
+      double bh[KS];
+#pragma unroll
+      for (int q = 0; q < KS; ++q) bh[q] = BH[o + ((int64_t)(4 * q) << 6)];
+      double acc[KS];
+      product(acc);
+      const double tot = item_sum(acc);
+      const int e = ((__double2hiint(tot) >> 20) & 0x7ff) - 1022;
+#pragma unroll
+      for (int q = 0; q < KS; ++q) {
+        double bt = ldexp(acc[q], -e);                   // beta_t
+        if (s >= L && s == top) bt = kq + 4 * q < N ? 1.0 : 0.0;     // uniform start
+        if (s < L && run) rows[o + ((int64_t)(4 * q) << 6)] = bt;
+        v[q] = (s >= L && s > top) ? 0.0 : bh[q] * bt;
+      }
+    }
+    if (run) vec_out(end);
   }
 }
 
