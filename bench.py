@@ -164,11 +164,15 @@ def main():
                 "forward_backward": 2 * 2 * N * N, "forward": 2 * N * N, "backward_posterior": 2 * N * N}
         achieved = alg[dom] * float(total) / (kavg[dom] * 1e-3) / 1e9
         traffic = None
+        stage_hbm = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tpath):     # HBM bytes per position measured with rocprofv3 --pmc (see file)
-            per_pos = json.load(open(tpath)).get("hbm_bytes_per_position", {}).get(dom)
+            tj = json.load(open(tpath)).get("hbm_bytes_per_position", {})
+            per_pos = tj.get(dom)
             if per_pos is not None:
                 traffic = per_pos * float(total)
+            # measured HBM bytes (PMC) over the live stage durations: which stages sit on the HBM roof
+            stage_hbm = {k: tj[k] * float(total) / (kavg[k] * 1e-3) / 1e9 for k in kavg if k in tj}
         out = {
             "metric": "genome positions/sec (Viterbi+posterior), 35 states x 10 tracks",
             "value": value, "unit": "positions/s", "n_gpus": world, "steps": args.steps,
@@ -185,6 +189,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "alg_bytes_per_position": alg[dom],
                          "whole_path_GBps": (K + 8 + 8 * N) * value / world / 1e9,
+                         "stage_hbm_traffic_GBps": stage_hbm,
                          # what binds instead of HBM: fp64 vector issue (78.6 TFLOP/s peak on MI355X)
                          "valu_f64": {"achieved": flop.get(dom, 0) * float(total) / (kavg[dom] * 1e-3) / 1e12,
                                       "peak": 78.6, "unit": "TFLOP/s",
