@@ -743,7 +743,7 @@ static void launch_vit_spec(tehmm_batch *b, const tehmm_model *m, const Interval
 template <int NT>
 static void launch_vit_fix(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em,
                            const VitChunks &vc, bool segmin, hipStream_t st) {
-  size_t lds = ((size_t)3 * 64 * (NT + 1) + 2 * 65 * (NT + 2) + (size_t)m->lds_rows * NT + 8) * sizeof(double);
+  size_t lds = ((size_t)3 * 32 * (NT + 1) + 2 * 33 * (NT + 2) + (size_t)m->lds_rows * NT + 8) * sizeof(double);   // CPB = 32
   allow_lds(k_vit_fix<NT, false>, lds);
   allow_lds(k_vit_fix<NT, true>, lds);
   if (segmin)
@@ -1048,7 +1048,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   // Enqueue order: Viterbi speculation pass 0 -> the whole posterior pipeline (async on its own
   // streams) -> host binade assignment (needs pass 0) -> rest of the Viterbi pipeline.
   const int CS = spec_chunk_size();
-  const bool spec_ok = coop && CS > 0 && m->NP <= 44 && b->total >= 2 * (int64_t)CS;
+  const bool spec_ok = coop && CS > 0 && m->NP <= 64 && b->total >= 2 * (int64_t)CS;
   const bool vit = flags & TEHMM_EVAL_VITERBI, postr = flags & TEHMM_EVAL_POSTERIOR;
   const bool vspec = vit && spec_ok && !ratio, fspec = postr && spec_ok;
   if (vspec || fspec) {

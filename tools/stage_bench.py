@@ -10,7 +10,7 @@ from tehmm_amd.engine import HipBatch, HipModel
 
 mb = float(sys.argv[1]) if len(sys.argv) > 1 else 100.0
 dev = torch.device("cuda", 0)
-model = synth.make_model(bench.N_STATES, synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=0)
+model = synth.make_model(int(os.environ.get("STATES", bench.N_STATES)), synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=0)
 total = int(mb * 1e6)
 lens = synth.interval_lengths(total, 200_000, 2_000_000, seed=1000)
 offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
