@@ -121,6 +121,7 @@ struct SpecWork {
 // item (sub-chunk) bookkeeping and item-interleaved buffers of the lane = item passes
 struct LaneWork {
   int L = 0, CS = 0, NP = 0, n_items = 0, n_groups = 0;
+  bool no_vlane = false;      // the fp64 log rows did not fit when the workspaces were sized
   std::vector<int> h_iv;
   std::vector<int64_t> h_t0, h_first;
   int64_t h_first_item(int id) const { return h_first[(size_t)id]; }
@@ -131,6 +132,8 @@ struct LaneWork {
   // Viterbi lane passes
   DBuf<double> vpre, vend, vgain, vtierows, vpiecemin, qtabs;
   DBuf<float> B32;
+  DBuf<VitChunks> d_vc;       // device copies of the argument tables of k_vit_lane
+  DBuf<VitItems> d_vi;
   DBuf<int> vbad, vntie, vties, wk_g, wk_e;
 };
 
@@ -884,15 +887,15 @@ static void launch_vit_lane(tehmm_batch *b, const tehmm_model *m, const Interval
   const LaneGeom lg = lane_geom(lw);
   const VitItems vi = lane_vit_items(lw);
   if (n_work <= 0) return;
+  (void)lw.d_vc.upload(&vc, 1);
+  (void)lw.d_vi.upload(&vi, 1);
   const dim3 grid((n_work + 3) / 4);
   if (quant) {
-    hipLaunchKernelGGL((k_vit_lane<NT, true>), grid, dim3(256), 0, st, iv, lg, vc, vi, m->N, Wu,
+    hipLaunchKernelGGL((k_vit_lane<NT, true>), grid, dim3(256), 0, st, iv, lg, (const VitChunks *)lw.d_vc.p,
+                       (const VitItems *)lw.d_vi.p, m->N, Wu,
                        (const int *)lw.wk_g.p, (const int *)lw.wk_e.p, n_work, (const double *)lw.qtabs.p, e0,
-                       (const double *)lw.B.p, b->tb.p);
-  } else
-    hipLaunchKernelGGL((k_vit_lane<NT, false>), grid, dim3(256), 0, st, iv, lg, vc, vi, m->N, Wu,
-                       (const int *)nullptr, (const int *)nullptr, n_work, (const double *)m->ltG.p, 0,
-                       (const double *)lw.B.p, b->tb.p);
+                       (const double *)lw.B.p, std::getenv("TEHMM_DBG_NOTB") ? (uint8_t *)nullptr : b->tb.p);
+  }
 }
 
 template <int NT>
@@ -1060,22 +1063,25 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   const EmisTab emg = without_lds_tables(em);
   const int eV = 0, eP = 5;
   int LS = ((vspec || fspec) && m->NP <= 36) ? lane_sub_size(CS, b->total) : 0;   // 4 * NP VGPRs of state
-  if (LS > 0 && !b->lw.AL.p && !b->lw.B.p) {
-    // the item-interleaved buffers (emission rows, alpha', beta': 3-4 x 8 * NP bytes per position) must
-    // fit next to the results; otherwise stay with the [T][N] speculative passes
+  // The lane = item Viterbi passes (TEHMM_LANE_VIT, default on) additionally need the fp64 log rows.
+  const char *lvs = std::getenv("TEHMM_LANE_VIT");
+  bool want_vlane = !(lvs && std::atoi(lvs) == 0);
+  if (LS > 0 && !b->lw.AL.p && !b->lw.B.p && !b->lw.B32.p) {
+    // the item-interleaved buffers (emission rows in up to three forms, alpha', beta': 8 * NP bytes per
+    // position each, 4 * NP for the float rows) must fit next to the results; otherwise do without the
+    // fp64 log rows, and failing that stay with the [T][N] speculative passes
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    const double need = (double)b->total * m->NP * 8.0 * 4.7;
-    if (need > 0.85 * (double)free_b) LS = 0;
+    const double per = (double)b->total * m->NP * 8.0;
+    b->lw.no_vlane = per * 5.7 > 0.85 * (double)free_b;
+    if (per * 4.7 > 0.85 * (double)free_b) LS = 0;
   }
-  // The lane = item Viterbi passes are opt-in (TEHMM_LANE_VIT=1): bit-exact, but on gfx950 their quantised
-  // pass is instruction-fetch bound and not yet faster than the lane = state pass.
-  const char *lvs = std::getenv("TEHMM_LANE_VIT");
-  const bool vlane = vspec && LS > 0 && lvs && std::atoi(lvs) != 0, flane = fspec && LS > 0;
+  if (b->lw.no_vlane) want_vlane = false;
+  const bool vlane = vspec && LS > 0 && want_vlane, flane = fspec && LS > 0;
   // P0 (binade placement) as a packed-float lane pass over float emission rows; TEHMM_LANE_P0=0 keeps
   // the fp64 lane = state pass
   const char *lp0 = std::getenv("TEHMM_LANE_P0");
-  const bool glane = vspec && !vlane && LS > 0 && !(lp0 && std::atoi(lp0) == 0);
+  const bool glane = vspec && LS > 0 && (vlane || !(lp0 && std::atoi(lp0) == 0));
   const char *wus = std::getenv("TEHMM_LANE_WARMUP");
   const int WuF = std::min(LS, std::max(1, wus ? std::atoi(wus) : 64));       // forward / backward warm-up
   const int WuV = std::min(LS, 64);                                            // Viterbi warm-up (multiple of 32)
@@ -1092,7 +1098,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   // posterior pipeline is released behind them (event), so that its wide kernels run next to the
   // Viterbi fix-up chain instead of competing with the passes that chain is waiting for (its emission
   // rows, which depend on nothing, are computed up front).
-  const bool defer_post = vit && postr && vspec && !vlane;
+  const bool defer_post = vit && postr && vspec;
   if (postr) (void)hipEventRecord(b->ev[eP], b->sP);
   if (vlane || glane) {
     // emission rows of every position, once, item-interleaved (log rows for Viterbi, linear for fwd/bwd)
@@ -1113,13 +1119,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     vc.iv = sw.iv.p; vc.t0 = sw.t0.p; vc.first = sw.first.p; vc.n = sw.n_chunks; vc.CS = CS;
     vc.e = sw.e.p; vc.gain = sw.gain.p; vc.ok = sw.ok.p; vc.wmin = sw.wmin.p; vc.rows = sw.rows.p;
     vc.ntie = sw.ntie.p; vc.ties = sw.ties.p; vc.tierows = sw.tierows.p; vc.segmin = sw.segmin.p;
-    if (vlane) {
-#define CALL(NT_) launch_vit_lane<NT_>(b, m, iv, vc, false, WuV, lw.n_groups, 0, st)
-      TEHMM_NT_DISPATCH(m->NP, CALL)
-#undef CALL
-      gain.resize((size_t)std::max(1, lw.n_groups) * 64);
-      HIPCHK(hipMemcpyAsync(gain.data(), lw.vgain.p, gain.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-    } else if (glane) {
+    if (glane) {
 #define CALL(NT_) launch_gain_lane<NT_>(b, m, iv, CS, WuV, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
@@ -1313,6 +1313,11 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
       (void)hipEventRecord(b->ev[eV + 3], st);
+      if (defer_post) {
+        (void)hipStreamWaitEvent(b->sP, b->ev[eV + 3], 0);
+        rc = enqueue_posterior();
+        if (rc) return rc;
+      }
 #define CALL(NT_) launch_vit_fix<NT_>(b, m, iv, em, vc, true, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL

@@ -133,7 +133,7 @@ void k_fb_lane(IntervalTab iv, LaneGeom lg, int N, int CS, int Wu, const double 
 #pragma unroll
     for (int i = 0; i < BLK; ++i) t[0][i] = tp[i];
     double a[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int b = 0; b < NB; ++b) {
       const int og = (b * 4) / NT, f0 = (b * 4) % NT;
       const double *tc = t[b & 1];
@@ -576,8 +576,8 @@ struct VitItems {
 };
 
 template <int NT, bool QUANT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_vit_lane(IntervalTab iv, LaneGeom lg, VitChunks vc, VitItems vi, int N, int Wu, const int *wk_g,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItems *vip, int N, int Wu, const int *wk_g,
                 const int *wk_e, int n_work, const double *__restrict__ tabs, int e0,
                 const double *__restrict__ B, uint8_t *tb) {
   const int lane = threadIdx.x & 63;
@@ -585,16 +585,20 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, VitChunks vc, VitItems vi, int N, i
   if (wk >= n_work) return;
   const int g = QUANT ? wk_g[wk] : wk;
   const int e = QUANT ? wk_e[wk] : 0;
-  const int L = lg.L, CS = vc.CS;
+  // the chunk / item tables are reached through pointers that are re-read where they are needed (rare
+  // paths): as by-value arguments their 22 pointers stay in SGPRs across the unrolled step and spill
+  auto VC = [&]() { const VitChunks *q = vcp; asm volatile("" : "+s"(q)); return *q; };
+  auto VI = [&]() { const VitItems *q = vip; asm volatile("" : "+s"(q)); return *q; };
+  const int L = lg.L, CS = vcp->CS;
   const int64_t item = (int64_t)g * 64 + lane;
   const bool valid = item < lg.n_items;
   const int id = valid ? lg.item_iv[item] : 0;
   const int64_t t0 = valid ? lg.item_t0[item] : 0;
   const int64_t T = iv.len[id], p0 = iv.pos0[id];
   const int64_t ct0 = (t0 / CS) * CS;
-  const int64_t c = vc.first[id] + t0 / CS;
+  const int64_t c = vcp->first[id] + t0 / CS;
   bool run = valid && ct0 > 0 && ct0 + CS <= T;      // first chunk and ragged tail: exact chain only
-  if (QUANT) run = run && vc.e[c] == e;
+  if (QUANT) run = run && vcp->e[c] == e;
   if (!__any(run)) return;
   const int64_t nb = run ? item - 1 : item;
   const_f64 *tab0 = (const_f64 *)(size_t)tabs + (QUANT ? (int64_t)(e - e0) * NT * NT : 0);
@@ -641,7 +645,7 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, VitChunks vc, VitItems vi, int N, i
     double Wn[NT];
     double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
     double bc[4];
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int b = 0; b < NB; ++b) {
       const int og = (b * 4) / NT, f0 = (b * 4) % NT;
       const double *tc = t[b & 1];
@@ -707,7 +711,7 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, VitChunks vc, VitItems vi, int N, i
         }
       }
       // traceback bytes of this group (a tie position gets garbage: the exact chain rewrites it)
-      if (QUANT && run && official) tb32[(p0 + t0 + s) * (NT / 4) + og] = pw;
+      if (QUANT && run && official && tb32) tb32[(p0 + t0 + s) * (NT / 4) + og] = pw;
       // pin the tie reduction to its group: left to itself the scheduler sinks all 36 of them to the end
       // of the step and keeps the whole emission row alive for it
       if (QUANT) asm volatile("" : "+v"(tmin));
@@ -737,6 +741,7 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, VitChunks vc, VitItems vi, int N, i
       if (pending) {
         if (run && s - 1 >= 0) {
           if (nt < TEHMM_LANE_MAXTI) {
+            const VitItems vi = VI();
             vi.ties[item * TEHMM_LANE_MAXTI + nt] = s - 1;
             double *tr = vi.tierows + (item * TEHMM_LANE_MAXTI + nt) * NT;
 #pragma unroll
@@ -767,7 +772,7 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, VitChunks vc, VitItems vi, int N, i
       }
     }
     if (s >= 0 && run) {
-      double *row = vc.rows + ((int64_t)c * (CS / TEHMM_VROW) + (t0 - ct0 + s) / TEHMM_VROW) * NT;
+      double *row = VC().rows + ((int64_t)c * (CS / TEHMM_VROW) + (t0 - ct0 + s) / TEHMM_VROW) * NT;
 #pragma unroll
       for (int j = 0; j < NT; ++j) row[j] = W[j] * 0.015625 + base;
     }
@@ -788,7 +793,7 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, VitChunks vc, VitItems vi, int N, i
   for (int s = -Wu; s < L; ++s) {                       // one loop: the unrolled step exists once
     close_piece(s);
     if (s == 0) {
-      if (run) vec_out(vi.pre);
+      if (run) vec_out(VI().pre);
       pmin = INFINITY;
       if (!QUANT) g0 = vec_max();
     }
@@ -801,6 +806,7 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, VitChunks vc, VitItems vi, int N, i
   }
   close_piece(L);
   if (run) {
+    const VitItems vi = VI();
     vec_out(vi.end);
     if (QUANT) {
       vi.ntie[item] = nt;

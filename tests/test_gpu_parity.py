@@ -280,10 +280,12 @@ def test_fused_random_shapes(hip, seed):
 CHUNK_CONFIGS = [
     {"TEHMM_SPEC_CHUNK": "0"},                                                  # cooperative kernels only
     {"TEHMM_SPEC_CHUNK": "128", "TEHMM_LANE_SUB": "0"},                         # lane = state speculation
-    {"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "64"},                        # lane = item fwd/bwd
-    {"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "128", "TEHMM_LANE_WARMUP": "24"},   # short warm-up: links fail
-    {"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "64", "TEHMM_LANE_VIT": "1"},  # lane = item Viterbi too
-    {"TEHMM_SPEC_CHUNK": "512", "TEHMM_LANE_SUB": "256", "TEHMM_LANE_VIT": "1"},
+    {"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "64", "TEHMM_LANE_VIT": "0"},  # lane = item fwd/bwd + P0
+    {"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "128", "TEHMM_LANE_WARMUP": "24",
+     "TEHMM_LANE_VIT": "0", "TEHMM_LANE_P0": "0"},                              # short warm-up: links fail
+    {"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "64"},                        # + lane = item exact Viterbi
+    {"TEHMM_SPEC_CHUNK": "512", "TEHMM_LANE_SUB": "256", "TEHMM_LANE_MFMA": "1"},
+    {"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "128", "TEHMM_LANE_WARMUP": "24", "TEHMM_FB_RUNS": "0"},
 ]
 
 
@@ -296,7 +298,8 @@ def test_chunk_parallel_paths(hip, monkeypatch, cfg, N):
     from tehmm_amd import synth
     from tehmm_amd.engine import HipBatch, HipModel
     from oracle import oracle
-    for k in ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_LANE_VIT"):
+    for k in ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_LANE_VIT", "TEHMM_LANE_P0",
+              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in CHUNK_CONFIGS[cfg].items():
         monkeypatch.setenv(k, v)
