@@ -289,6 +289,35 @@ CHUNK_CONFIGS = [
 ]
 
 
+@pytest.mark.parametrize("cfg", [1, 2, 4])
+def test_chunk_parallel_sparse_model(hip, monkeypatch, cfg):
+    """The chunk-parallel paths on a model with -1e100 (LOGZERO) transitions: states sitting at -1e100 are
+    outside every binade, so the exact chains must refuse the speculative results wherever such a
+    state is alive -- and the answers stay those of the reference."""
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    from oracle import oracle
+    for k in ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_LANE_VIT", "TEHMM_LANE_P0",
+              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in CHUNK_CONFIGS[cfg].items():
+        monkeypatch.setenv(k, v)
+    for sparse, seed in ((0.3, 5), (0.7, 6)):
+        model = synth.make_model(35, seed=seed, sparse=sparse)
+        lens = [300, 5000, 30000]
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        obs = synth.sample_obs(model, int(offs[-1]), seed=seed, missing=0.03)
+        hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, 1.0, model.symbols_per_track)
+        hb = HipBatch(obs, offs)
+        res = hm.eval(hb, viterbi=True, posterior=True)
+        p_o, vlp_o, flp_o, post_o = oracle.eval_batch(obs, offs, model.log_probs, model.log_startprob,
+                                                      model.log_transmat, 1.0, None, n_threads=4)
+        assert_array_equal(hb.paths(), p_o)
+        assert_array_equal(res["viterbi_logprob"], vlp_o)
+        assert_allclose(res["forward_logprob"], flp_o, rtol=RTOL)
+        assert_allclose(hb.posteriors(), post_o, rtol=RTOL, atol=1e-15)
+
+
 @pytest.mark.parametrize("cfg", range(len(CHUNK_CONFIGS)))
 @pytest.mark.parametrize("N", [35, 20, 7, 50])
 def test_chunk_parallel_paths(hip, monkeypatch, cfg, N):
@@ -309,18 +338,22 @@ def test_chunk_parallel_paths(hip, monkeypatch, cfg, N):
     offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     obs = synth.sample_obs(model, int(offs[-1]), seed=cfg, missing=0.03)
     hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, 1.0, model.symbols_per_track)
-    hb = HipBatch(obs, offs)
+    # N = 20 runs with segment ratios: decode applies them to the self-transitions (sequential exact
+    # Viterbi kernel), the posterior ignores them (chunk-parallel passes) -- quirks Q11 / Q12
+    ratios = synth.random_ratios(int(offs[-1]), seed=cfg) if N == 20 else None
+    hb = HipBatch(obs, offs, ratios)
     for _ in range(2):                      # second call reuses the chunk / item workspaces
         res = hm.eval(hb, viterbi=True, posterior=True)
     p_o, vlp_o, flp_o, post_o = oracle.eval_batch(obs, offs, model.log_probs, model.log_startprob,
-                                                  model.log_transmat, 1.0, None, n_threads=4)
+                                                  model.log_transmat, 1.0, ratios, n_threads=4)
     assert_array_equal(hb.paths(), p_o)
     assert_array_equal(res["viterbi_logprob"], vlp_o)
     assert_allclose(res["forward_logprob"], flp_o, rtol=RTOL)
     assert_allclose(hb.posteriors(), post_o, rtol=RTOL, atol=1e-15)
     t = hb.timing()
-    if CHUNK_CONFIGS[cfg]["TEHMM_SPEC_CHUNK"] != "0":
+    if CHUNK_CONFIGS[cfg]["TEHMM_SPEC_CHUNK"] != "0" and ratios is None:
         # the long intervals reach |V| >= 2^18, so chunks really are jumped over (not just run exactly)
         assert "viterbi_speculate" in t and t["count:viterbi_exact_blocks"] > 0
         assert t["count:viterbi_chunk_jumps"] > 0
+    if CHUNK_CONFIGS[cfg]["TEHMM_SPEC_CHUNK"] != "0":
         assert t["count:forward_chunk_jumps"] > 0 and t["count:backward_chunk_jumps"] > 0
