@@ -894,7 +894,7 @@ static void launch_vit_lane(tehmm_batch *b, const tehmm_model *m, const Interval
     hipLaunchKernelGGL((k_vit_lane<NT, true>), grid, dim3(256), 0, st, iv, lg, (const VitChunks *)lw.d_vc.p,
                        (const VitItems *)lw.d_vi.p, m->N, Wu,
                        (const int *)lw.wk_g.p, (const int *)lw.wk_e.p, n_work, (const double *)lw.qtabs.p, e0,
-                       (const double *)lw.B.p, std::getenv("TEHMM_DBG_NOTB") ? (uint8_t *)nullptr : b->tb.p);
+                       (const double *)lw.B.p, b->tb.p);
   }
 }
 
