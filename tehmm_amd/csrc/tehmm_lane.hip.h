@@ -505,8 +505,9 @@ __global__ void k_fb_runs(IntervalTab iv, FbChunks fc, const int *ok_f, const in
 template <int NT, bool EPS>
 __global__ __launch_bounds__(256) void k_combine_lane(IntervalTab iv, LaneGeom lg, int N, const double *al,
                                                       const double *be, double *post) {
-  __shared__ double tile[64 * (NT + 1)];
-  __shared__ double rs[64];
+  // two positions per round: tiles [2][64 items][NT + 1], row scales [2][64]
+  __shared__ double tile[2 * 64 * (NT + 1)];
+  __shared__ double rs[2 * 64];
   __shared__ int64_t pb[64];
   __shared__ int rlen[64];
   const int tid = threadIdx.x;
@@ -523,29 +524,39 @@ __global__ __launch_bounds__(256) void k_combine_lane(IntervalTab iv, LaneGeom l
     rlen[tid] = valid ? (int)min((int64_t)L, iv.len[id] - t0) : 0;
   }
   const double eps = 1.1920928955078125e-07;
-  const double epsden = 1.0 + (double)N * eps;
+  const double inv_epsden = 1.0 / (1.0 + (double)N * eps);
   __syncthreads();
-  for (int s = s0; s < s0 + 8; ++s) {
-    const int64_t o = (((int64_t)g * L + s) * NT) << 6;
-    for (int idx = tid; idx < NT * 64; idx += 256) {
-      const int j = idx >> 6, ln = idx & 63;
-      double p = 0.0;
-      if (s < rlen[ln]) p = al[o + idx] * be[o + idx];
-      tile[ln * (NT + 1) + j] = p;
+  for (int s = s0; s < s0 + 8; s += 2) {
+    // coalesced tile loads of both positions (NT * 64 doubles each), transposed into LDS
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t o = (((int64_t)g * L + s + h) * NT) << 6;
+      double *tl = tile + h * 64 * (NT + 1);
+      for (int idx = tid; idx < NT * 64; idx += 256) {
+        const int j = idx >> 6, ln = idx & 63;
+        double p = 0.0;
+        if (s + h < rlen[ln]) p = al[o + idx] * be[o + idx];
+        tl[ln * (NT + 1) + j] = p;
+      }
     }
     __syncthreads();
-    if (tid < 64) {
+    if (tid < 128) {                         // 1 / row sum of each of the 2 x 64 rows
+      const double *tr = tile + (tid >> 6) * 64 * (NT + 1) + (tid & 63) * (NT + 1);
       double t = 0.0;
-      for (int j = 0; j < N; ++j) t += tile[tid * (NT + 1) + j];
-      rs[tid] = t;
+      for (int j = 0; j < N; ++j) t += tr[j];
+      rs[tid] = 1.0 / t;
     }
     __syncthreads();
-    for (int idx = tid; idx < 64 * N; idx += 256) {
-      const int r = idx / N, col = idx - r * N;
-      if (s < rlen[r]) {
-        double pr = tile[r * (NT + 1) + col] / rs[r];
-        if (EPS) pr = (pr + eps) / epsden;
-        post[(pb[r] + s) * N + col] = pr;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const double *tl = tile + h * 64 * (NT + 1);
+      for (int idx = tid; idx < 64 * N; idx += 256) {
+        const int r = idx / N, col = idx - r * N;
+        if (s + h < rlen[r]) {
+          double pr = tl[r * (NT + 1) + col] * rs[h * 64 + r];
+          if (EPS) pr = (pr + eps) * inv_epsden;
+          post[(pb[r] + s + h) * N + col] = pr;
+        }
       }
     }
     __syncthreads();
