@@ -1084,7 +1084,8 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   const bool glane = vspec && LS > 0 && (vlane || !(lp0 && std::atoi(lp0) == 0));
   const char *wus = std::getenv("TEHMM_LANE_WARMUP");
   const int WuF = std::min(LS, std::max(1, wus ? std::atoi(wus) : 64));       // forward / backward warm-up
-  const int WuV = std::min(LS, 64);                                            // Viterbi warm-up (multiple of 32)
+  const char *wvs = std::getenv("TEHMM_LANE_WARMUP_VIT");
+  const int WuV = std::min(LS, std::max(32, ((wvs ? std::atoi(wvs) : 32) + 31) & ~31));   // Viterbi warm-up (multiple of 32)
   VitChunks vc;
   std::vector<double> gain;
   if (vit) (void)hipEventRecord(b->ev[eV], b->sV);
