@@ -357,3 +357,52 @@ def test_chunk_parallel_paths(hip, monkeypatch, cfg, N):
         assert t["count:viterbi_chunk_jumps"] > 0
     if CHUNK_CONFIGS[cfg]["TEHMM_SPEC_CHUNK"] != "0":
         assert t["count:forward_chunk_jumps"] > 0 and t["count:backward_chunk_jumps"] > 0
+
+
+def test_config_sizes_chunk_parallel_vs_sequential(hip, monkeypatch):
+    """BASELINE-size check (config 2's single 10 Mb interval + config-3 style 0.2-2 Mb intervals, 35
+    states x 10 tracks, ~24 Mb): the chunk-parallel default against the sequential cooperative kernels
+    -- which the tests above hold to the oracle -- on the same batch.  Viterbi paths and scores must
+    be bit-identical, forward log-likelihoods agree to 1e-9, posterior rows (sampled row ranges: interval
+    starts and ends, chunk and item boundaries, interior) to 1e-6, every row sums to 1."""
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    for k in ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_LANE_VIT", "TEHMM_LANE_P0",
+              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS"):
+        monkeypatch.delenv(k, raising=False)
+    model = synth.make_model(35, synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=0)
+    rs = np.random.RandomState(123)
+    lens = [10_000_000] + [int(x) for x in rs.randint(200_000, 2_000_000, size=13)]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    total = int(offs[-1])
+    piece = synth.sample_obs(model, 100_000, seed=3)
+    obs = np.tile(piece, (total // 100_000 + 1, 1))[:total].copy()
+    noise = rs.rand(total) < 0.25
+    for k, sk in enumerate(model.symbols_per_track):
+        col = obs[:, k]
+        col[noise] = rs.randint(1, sk + 1, size=int(noise.sum()))
+    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, 1.0, model.symbols_per_track)
+
+    def run():
+        hb = HipBatch(obs, offs)
+        res = hm.eval(hb, viterbi=True, posterior=True)
+        spans = []
+        for i in range(len(lens)):
+            a, b = int(offs[i]), int(offs[i + 1])
+            spans += [(a, a + 700), (b - 700, b), (a + 4096 - 300, a + 4096 + 300), ((a + b) // 2, (a + b) // 2 + 600)]
+        post = [hb.posteriors(35, r0, r1) for r0, r1 in spans]
+        out = (hb.paths(), res["viterbi_logprob"].copy(), res["forward_logprob"].copy(), post, hb.timing())
+        hb.close()
+        return out
+
+    p_a, v_a, f_a, post_a, t_a = run()
+    assert t_a["count:viterbi_chunk_jumps"] > 1000 and t_a["count:forward_chunk_jumps"] >= len(lens)
+    monkeypatch.setenv("TEHMM_SPEC_CHUNK", "0")
+    p_b, v_b, f_b, post_b, t_b = run()
+    assert "viterbi_speculate" not in t_b
+    assert_array_equal(p_a, p_b)
+    assert_array_equal(v_a, v_b)
+    assert_allclose(f_a, f_b, rtol=1e-9)
+    for x, y in zip(post_a, post_b):
+        assert_allclose(x, y, rtol=RTOL, atol=1e-15)
+        assert_allclose(x.sum(axis=1), 1.0, rtol=1e-9)
