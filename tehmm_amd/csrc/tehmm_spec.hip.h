@@ -683,7 +683,11 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
       const int pg = DIR == 0 ? 31 : 32;                        // check step inside the block
       const int64_t tg = DIR == 0 ? lo + pg : cur - 1 - pg;     // its position
       // LANE: a jump runs to the end of the whole run of linked chunks, not just of this chunk
-      const int64_t cj = !LANE ? c : (DIR == 0 ? cfirst + (fc.runend_f[c] - cfirst) : cfirst + (fc.runstart_b[c] - cfirst));
+      int64_t cj = c;
+      if (LANE) {                                   // (clamped: a jump can only move in chain direction)
+        cj = DIR == 0 ? max(c, (int64_t)fc.runend_f[c]) : min(c, (int64_t)fc.runstart_b[c]);
+        cj = DIR == 0 ? min(cj, (int64_t)fc.first[id + 1] - 1) : max(cj, cfirst);
+      }
       const int64_t target = DIR == 0 ? fc.t0[cj] + fc.CS : fc.t0[cj];      // key of the block after a jump
       double srow = 0.0;
       if (spec) srow = live ? brow[(tg - lo) * rstride] : 0.0;  // speculative row, before overwriting
