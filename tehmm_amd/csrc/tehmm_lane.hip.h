@@ -565,15 +565,23 @@ __global__ __launch_bounds__(256) void k_combine_lane(IntervalTab iv, LaneGeom l
 
 
 // ==========================================================================================
-// Viterbi lane passes.  Same arithmetic as k_vit_spec (tehmm_spec.hip.h: plain fp64 for P0, the
-// binade's exact integer max-plus recurrence for P2), one item per lane.  P2 needs the quantised
-// transition table of the item's binade as scalar operands, so a wave is launched per (group,
-// binade) pair and lanes of another binade sit idle (binades change ~8 times per interval).
-//   P0 (QUANT = false): gain[item] = max W_end - max W_pre  (score gained over the official range by
-//       the converged vector: the host's prefix sums place every chunk in its binade);
-//   P2 (QUANT = true) : packed traceback bytes straight into tb[(pos0 + t) * NT + state], W rows at
-//       every 32nd position straight into vc.rows (lane frame), pre / end vectors, ties, per-piece
-//       minima.  k_vit_stitch then links the items of a chunk into segments for k_vit_fix.
+// Exact quantised Viterbi pass (P2 of tehmm_spec.hip.h) as a lane = item pass: the binade's exact
+// integer max-plus recurrence, one item per lane.  It needs the quantised transition table of the item's
+// binade as scalar operands, so a wave is launched per (group, binade) pair and lanes of another binade
+// sit idle (binades change ~8 times per interval); waves are sorted by binade so that co-resident waves
+// share one table in the scalar cache.  Outputs: packed traceback dwords straight into
+// tb[(pos0 + t) * NT + state], W rows at every 16th position straight into vc.rows (lane frame), pre /
+// end vectors, ties, per-piece minima; k_vit_stitch then links the items of a chunk into segments for
+// k_vit_fix.  (QUANT = false is the same recurrence in plain fp64; P0 uses k_vit_gain_lane instead.)
+//
+// What the compiler needs to be told here (each cost a factor when it was missing):
+//   * the block loop must be FULLY unrolled (`#pragma clang loop unroll(full)`): a partial unroll
+//     indexes W / t dynamically and every step goes through scratch;
+//   * no per-element booleans in the unrolled body: each v_cmp pins a scalar mask, 36 of them spill
+//     thousands of SGPRs -- ties are found by a running minimum and ONE compare, dead states by maxNum;
+//   * the rarely used chunk / item tables come through pointers re-read in the rare paths;
+//   * 340 registers: one wave per SIMD.  (Parking the successor vector in LDS for a second wave loses:
+//     LDS traffic shares lgkmcnt with the scalar operand stream.)
 // ==========================================================================================
 #define TEHMM_LANE_MAXTI 8
 struct VitItems {
