@@ -190,6 +190,10 @@ def main():
                          "alg_bytes_per_position": alg[dom],
                          "whole_path_GBps": (K + 8 + 8 * N) * value / world / 1e9,
                          "stage_hbm_traffic_GBps": stage_hbm,
+                         # the stage that sits highest on the HBM roof (measured bytes / live duration)
+                         "busiest_hbm_stage": (lambda k: {"kernel": k, "achieved": stage_hbm[k], "unit": "GB/s",
+                                                          "frac": stage_hbm[k] / HBM_PEAK_GBPS})(
+                             max(stage_hbm, key=stage_hbm.get)) if stage_hbm else None,
                          # what binds instead of HBM: fp64 vector issue (78.6 TFLOP/s peak on MI355X)
                          "valu_f64": {"achieved": flop.get(dom, 0) * float(total) / (kavg[dom] * 1e-3) / 1e12,
                                       "peak": 78.6, "unit": "TFLOP/s",
