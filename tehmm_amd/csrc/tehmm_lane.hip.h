@@ -625,6 +625,7 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItem
   const double M = QUANT ? ldexp(1.5, e) : 0.0;          // fl(z + M) - M rounds z to the grid u
   const double half_u = 0.5 * u;
   const double inv_u = QUANT ? ldexp(1.0, 52 - e) : 0.0;
+  const double wlim = QUANT ? -ldexp(1.0, e + 1) : -INFINITY;
   double W[NT];                                          // QUANT: 64 x (value - base); plain: value
 #pragma unroll
   for (int j = 0; j < NT; ++j) W[j] = j < N ? 0.0 : -INFINITY;
@@ -747,6 +748,9 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItem
 #pragma unroll
       for (int j = 0; j < NT; ++j) wl = fmin(wl, (j < NT - 8 || j < N) ? W[j] : INFINITY);
       if (!tie) pmin = fmin(pmin, wl * 0.015625 + base);
+      // W = 64 (value - base) + index bits must stay exactly representable: |W| < 2^53 u = 2^(e+1).  A state
+      // that falls further behind within a re-basing window (or dies) makes the item unusable.
+      bad = bad | (wl <= wlim);
     } else {
 #pragma unroll
       for (int j = 0; j < NT; ++j) W[j] = Wn[j];

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const double u = QUANT ? ldexp(1.0, e - 52) : 0.0;
     const double M = QUANT ? ldexp(1.5, e) : 0.0;        // fl(z + M) - M rounds z to the grid u
     const double half_u = 0.5 * u;
+    const double wlim = QUANT ? -ldexp(1.0, e + 1) : -INFINITY;
     bool bad = false;
     // column `lane` of the transition table, quantised and carrying the from-index in its low bits
     double ltc[NT];
@@ -172,6 +173,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const bool fin = m > -INFINITY;
             const int arg = fin ? 63 - (int)r : 0;
             W = fin ? (m - r * u) + b : -INFINITY;
+            // W = 64 (value - base) + index bits must stay exactly representable: |W| < 2^53 u = 2^(e+1)
+            if (live && W <= wlim && W > -INFINITY) bad = true;
             if (live) tb[(p0 + t) * NT + lane] = (uint8_t)arg;
           }
           if ((p & (TEHMM_VROW - 1)) == TEHMM_VROW - 1) {

@@ -318,6 +318,38 @@ def test_chunk_parallel_sparse_model(hip, monkeypatch, cfg):
         assert_allclose(hb.posteriors(), post_o, rtol=RTOL, atol=1e-15)
 
 
+@pytest.mark.parametrize("cfg", [1, 2, 4])
+def test_chunk_parallel_deep_emission_drops(hip, monkeypatch, cfg):
+    """Emission entries of -3e4 .. -2e5 (a symbol some states all but exclude): a state that falls that far
+    behind inside one re-basing window stays inside its fp64 binade but no longer fits the exact
+    integer representation of the quantised pass (index bits + 64 x offset < 2^53 u).  The speculative
+    kernels must notice and leave such stretches to the exact chain."""
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    from oracle import oracle
+    for k in ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_LANE_VIT", "TEHMM_LANE_P0",
+              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in CHUNK_CONFIGS[cfg].items():
+        monkeypatch.setenv(k, v)
+    model = synth.make_model(12, seed=21)
+    lp = model.log_probs.copy()
+    lp[0, 0:4, 1] = -3.0e4          # track 0, symbol 1, states 0..3
+    lp[1, 5:7, 2] = -2.0e5          # track 1, symbol 2, states 5, 6
+    lens = [40000, 70000]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = synth.sample_obs(model, int(offs[-1]), seed=4, missing=0.02)
+    hm = HipModel(model.log_transmat, model.log_startprob, lp, 1.0, model.symbols_per_track)
+    hb = HipBatch(obs, offs)
+    res = hm.eval(hb, viterbi=True, posterior=True)
+    p_o, vlp_o, flp_o, post_o = oracle.eval_batch(obs, offs, lp, model.log_startprob, model.log_transmat,
+                                                  1.0, None, n_threads=4)
+    assert_array_equal(hb.paths(), p_o)
+    assert_array_equal(res["viterbi_logprob"], vlp_o)
+    assert_allclose(res["forward_logprob"], flp_o, rtol=RTOL)
+    assert_allclose(hb.posteriors(), post_o, rtol=RTOL, atol=1e-15)
+
+
 @pytest.mark.parametrize("cfg", range(len(CHUNK_CONFIGS)))
 @pytest.mark.parametrize("N", [35, 20, 7, 50])
 def test_chunk_parallel_paths(hip, monkeypatch, cfg, N):
