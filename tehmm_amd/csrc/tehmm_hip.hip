@@ -1076,6 +1076,12 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     b->lw.no_vlane = per * 5.7 > 0.85 * (double)free_b;
     if (per * 4.7 > 0.85 * (double)free_b) LS = 0;
   }
+  if (LS > 0 && want_vlane && !b->lw.no_vlane && !b->lw.B.p && (b->lw.AL.p || b->lw.B32.p)) {
+    // workspaces of an earlier call exist already: the fp64 (+ float) log rows must still fit
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    if ((double)b->total * m->NP * 8.0 * 1.6 > 0.85 * (double)free_b) b->lw.no_vlane = true;
+  }
   if (b->lw.no_vlane) want_vlane = false;
   const bool vlane = vspec && LS > 0 && want_vlane, flane = fspec && LS > 0;
   // P0 (binade placement) as a packed-float lane pass over float emission rows; TEHMM_LANE_P0=0 keeps

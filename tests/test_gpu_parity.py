@@ -438,3 +438,40 @@ def test_config_sizes_chunk_parallel_vs_sequential(hip, monkeypatch):
     for x, y in zip(post_a, post_b):
         assert_allclose(x, y, rtol=RTOL, atol=1e-15)
         assert_allclose(x.sum(axis=1), 1.0, rtol=1e-9)
+
+
+def test_chunk_parallel_call_sequences(hip, monkeypatch):
+    """The same batch evaluated posterior-only, Viterbi-only, both, with changing chunk / item sizes in
+    between (workspaces are built incrementally and rebuilt when the geometry changes)."""
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    from oracle import oracle
+    for k in ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_LANE_VIT", "TEHMM_LANE_P0",
+              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS"):
+        monkeypatch.delenv(k, raising=False)
+    model = synth.make_model(35, seed=9)
+    lens = [3000, 26000, 50000]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = synth.sample_obs(model, int(offs[-1]), seed=2, missing=0.03)
+    p_o, vlp_o, flp_o, post_o = oracle.eval_batch(obs, offs, model.log_probs, model.log_startprob,
+                                                  model.log_transmat, 1.0, None, n_threads=4)
+    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, 1.0, model.symbols_per_track)
+    hb = HipBatch(obs, offs)
+    steps = [({"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "64"}, False, True),
+             ({"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "64"}, True, False),
+             ({"TEHMM_SPEC_CHUNK": "512", "TEHMM_LANE_SUB": "128"}, True, True),
+             ({"TEHMM_SPEC_CHUNK": "512", "TEHMM_LANE_SUB": "128", "TEHMM_LANE_VIT": "0"}, True, True),
+             ({"TEHMM_SPEC_CHUNK": "0"}, True, True),
+             ({"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "256"}, True, True)]
+    for env, vit, post in steps:
+        for k in ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_VIT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        res = hm.eval(hb, viterbi=vit, posterior=post)
+        if vit:
+            assert_array_equal(hb.paths(), p_o)
+            assert_array_equal(res["viterbi_logprob"], vlp_o)
+        if post:
+            assert_allclose(res["forward_logprob"], flp_o, rtol=RTOL)
+            assert_allclose(hb.posteriors(), post_o, rtol=RTOL, atol=1e-15)
