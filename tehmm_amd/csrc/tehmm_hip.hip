@@ -1105,7 +1105,8 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   // posterior pipeline is released behind them (event), so that its wide kernels run next to the
   // Viterbi fix-up chain instead of competing with the passes that chain is waiting for (its emission
   // rows, which depend on nothing, are computed up front).
-  const bool defer_post = vit && postr && vspec;
+  const char *dfs = std::getenv("TEHMM_DEFER");
+  const bool defer_post = vit && postr && vspec && !(dfs && std::atoi(dfs) == 0);
   if (postr) (void)hipEventRecord(b->ev[eP], b->sP);
   if (vlane || glane) {
     // emission rows of every position, once, item-interleaved (log rows for Viterbi, linear for fwd/bwd)
@@ -1316,6 +1317,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
 #define CALL(NT_) launch_vit_lane<NT_>(b, m, iv, vc, true, WuV, n_work, emin, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
+
 #define CALL(NT_) launch_vit_stitch<NT_>(b, m, iv, vc, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL

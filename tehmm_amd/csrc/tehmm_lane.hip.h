@@ -272,7 +272,7 @@ void k_fb_lane(IntervalTab iv, LaneGeom lg, int N, int CS, int Wu, const double 
 typedef double lane_d4 __attribute__((ext_vector_type(4)));
 
 template <int NT, int DIR>
-__global__ __launch_bounds__(256) void k_fb_mfma(IntervalTab iv, LaneGeom lg, int N, int CS, int Wu,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_fb_mfma(IntervalTab iv, LaneGeom lg, int N, int CS, int Wu,
                                                  const double *__restrict__ tab /* A, [NT][NT] row-major */,
                                                  const double *__restrict__ BH, const double *__restrict__ MS,
                                                  double *rows, double *pre, double *end, double *slog32) {
