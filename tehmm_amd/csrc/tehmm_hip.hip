@@ -115,7 +115,8 @@ struct SpecWork {
   std::vector<int64_t> h_t0, h_first;
   DBuf<int> iv, e, ok, stats, ntie, ties;
   DBuf<int64_t> t0, first;
-  DBuf<double> gain, wmin, rows, tierows, scale, wstart, segmin;
+  DBuf<double> gain, wmin, rows, tierows, scale, wstart, segmin, offend, clk;
+  DBuf<int> clink;
 };
 
 // item (sub-chunk) bookkeeping and item-interleaved buffers of the lane = item passes
@@ -698,6 +699,10 @@ static int spec_prepare(tehmm_batch *b, const tehmm_model *m, int CS) {
   HIPCHK(sw.ties.alloc(nc * TEHMM_SPEC_MAXT));
   HIPCHK(sw.tierows.alloc(nc * TEHMM_SPEC_MAXT * (size_t)m->NP));
   HIPCHK(sw.segmin.alloc(nc * (TEHMM_SPEC_MAXT + 1)));
+  HIPCHK(sw.offend.alloc(nc));
+  HIPCHK(sw.clk.alloc(nc));
+  HIPCHK(sw.clink.alloc(nc));
+  HIPCHK(hipMemset(sw.clink.p, 0, nc * sizeof(int)));
   return TEHMM_OK;
 }
 
@@ -904,6 +909,12 @@ static void launch_vit_stitch(tehmm_batch *b, const tehmm_model *m, const Interv
   LaneWork &lw = b->lw;
   hipLaunchKernelGGL((k_vit_stitch<NT>), dim3((vc.n + 3) / 4), dim3(256), 0, st, iv, lane_geom(lw), vc,
                      lane_vit_items(lw), m->N);
+  const char *vl = std::getenv("TEHMM_VIT_RUNS");        // 0: one verification per chunk
+  if (vl && std::atoi(vl) == 0)
+    (void)hipMemsetAsync(vc.clink, 0, (size_t)vc.n * sizeof(int), st);
+  else
+    hipLaunchKernelGGL((k_vit_links<NT>), dim3((vc.n + 3) / 4), dim3(256), 0, st, iv, lane_geom(lw), vc,
+                       lane_vit_items(lw), m->N);
 }
 
 static LaneGeom lane_geom(const LaneWork &lw) {
@@ -1127,6 +1138,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     vc.iv = sw.iv.p; vc.t0 = sw.t0.p; vc.first = sw.first.p; vc.n = sw.n_chunks; vc.CS = CS;
     vc.e = sw.e.p; vc.gain = sw.gain.p; vc.ok = sw.ok.p; vc.wmin = sw.wmin.p; vc.rows = sw.rows.p;
     vc.ntie = sw.ntie.p; vc.ties = sw.ties.p; vc.tierows = sw.tierows.p; vc.segmin = sw.segmin.p;
+    vc.offend = sw.offend.p; vc.clink = sw.clink.p; vc.clk = sw.clk.p;
     if (glane) {
 #define CALL(NT_) launch_gain_lane<NT_>(b, m, iv, CS, WuV, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)

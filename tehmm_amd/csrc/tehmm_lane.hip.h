@@ -856,7 +856,7 @@ __global__ __launch_bounds__(256) void k_vit_stitch(IntervalTab iv, LaneGeom lg,
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= vc.n) return;
   if (vc.e[c] == TEHMM_SPEC_NONE) {
-    if (lane == 0) { vc.ok[c] = 0; vc.ntie[c] = 0; }
+    if (lane == 0) { vc.ok[c] = 0; vc.ntie[c] = 0; vc.offend[c] = 0.0; }
     return;
   }
   const int id = vc.iv[c];
@@ -920,6 +920,47 @@ __global__ __launch_bounds__(256) void k_vit_stitch(IntervalTab iv, LaneGeom lg,
     vc.segmin[(int64_t)c * (TEHMM_SPEC_MAXT + 1) + min(nT, TEHMM_SPEC_MAXT)] = segmin;
     vc.ntie[c] = nT;
     vc.ok[c] = (okc && nT <= TEHMM_SPEC_MAXT) ? 1 : 0;
+    vc.offend[c] = off_end;
+  }
+}
+
+// Links BETWEEN chunks (after k_vit_stitch, one wave per chunk): chunk c continues chunk c - 1 when both
+// are usable, live in the same binade and the vector before c's first position is the previous chunk's
+// end vector plus ONE constant (exactly).  k_vit_fix then lets a verified jump run on through the linked
+// chunks up to the next tie: one verification per run of chunks instead of one per chunk.
+template <int NT>
+__global__ __launch_bounds__(256) void k_vit_links(IntervalTab iv, LaneGeom lg, VitChunks vc, VitItems vi, int N) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= vc.n) return;
+  const int id = vc.iv[c];
+  bool cand = c > vc.first[id] && vc.e[c] != TEHMM_SPEC_NONE && vc.e[c - 1] == vc.e[c] && vc.ok[c] != 0 &&
+              vc.ok[c - 1] != 0;
+  int link = 0;
+  double lk = 0.0;
+  if (cand) {
+    const int L = lg.L;
+    const int64_t item0 = lg.ifirst[id] + vc.t0[c] / L;
+    const bool live = lane < N;
+    const int jl = min(lane, NT - 1);
+    auto at = [&](const double *p, int64_t item) { return p[((((item >> 6) * NT) + jl) << 6) + (item & 63)]; };
+    const double a = at(vi.pre, item0);                              // frame of c's first segment
+    const double bp = at(vi.end, item0 - 1) + vc.offend[c - 1];      // frame of c - 1's last segment
+    const bool both_dead = a == -INFINITY && bp == -INFINITY;
+    const double d = bp - a;
+    const double d0 = wave_max_live((both_dead || !live) ? -INFINITY : d, live);
+    const bool same = __all(!live || both_dead || d == d0) && d0 == d0 && d0 > -INFINITY && d0 < INFINITY;
+    // (an item of c - 1 that ended on a pending tie restarted from zeros: then its end vector is the zero
+    //  vector of a segment that begins at c's first position, which k_vit_stitch has recorded as a tie at
+    //  the chunk end -- such chunks do not link: their last "tie" is at CS)
+    if (same && vi.bad[item0 - 1] == 0 && vi.bad[item0] == 0) {
+      link = 1;
+      lk = d0;
+    }
+  }
+  if (lane == 0) {
+    vc.clink[c] = link;
+    vc.clk[c] = lk;
   }
 }
 

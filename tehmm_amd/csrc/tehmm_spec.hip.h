@@ -52,6 +52,10 @@ struct VitChunks {
   int *ties;              // P2: [chunk][MAXT] tie positions relative to t0, ascending
   double *tierows;        // P2: [chunk][MAXT][NT] W row of the position just before each tie
   double *segmin;         // lane passes: [chunk][MAXT + 1] lowest live W of each segment (its frame)
+  double *offend;         // lane passes: [chunk] segment-frame offset of the chunk's last item (k_vit_stitch)
+  int *clink;             // lane passes: [chunk] 1 = the chunk's first segment continues the previous
+                          //   chunk's last one (same binade, exact constant difference)
+  double *clk;            // lane passes: [chunk] that constant: frame(previous) = frame(this) + clk
 };
 #define TEHMM_SPEC_MAXT 32
 #define TEHMM_VROW 16             // spacing of the recorded W rows
@@ -293,7 +297,7 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
         const int64_t g = ct0 + ((cur + 12 - ct0) / TEHMM_VROW) * TEHMM_VROW + (TEHMM_VROW - 1);
         const int pg = (int)(g - cur);                          // in-block step of the check, 12..27
         int64_t target = ct0 + vc.CS;
-        double smin = 0.0;
+        double smin = 0.0, lkacc = 0.0;
         const double *trow = vc.rows + ((c * (vc.CS / TEHMM_VROW)) + (vc.CS / TEHMM_VROW - 1)) * NT;
         if (spec) {
           const int ntie = vc.ntie[c];
@@ -303,14 +307,33 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
             const int64_t tp = ct0 + tl[k];
             if (tp > g) { target = tp; trow = vc.tierows + (c * TEHMM_SPEC_MAXT + k) * NT; kseg = k; break; }
           }
-          if (SEGMIN) smin = vc.segmin[c * (TEHMM_SPEC_MAXT + 1) + kseg];
+          if (SEGMIN) {
+            smin = vc.segmin[c * (TEHMM_SPEC_MAXT + 1) + kseg];
+            // the segment may run on through the following chunks (lane passes link them exactly when they
+            // share the binade): walk to its first tie or to the end of the linked run.  lkacc turns
+            // values of a later chunk's first-segment frame into the frame of the check row's segment.
+            int64_t cc = c;
+            const int64_t c_end = vc.first[id + 1];
+            while (target == vc.t0[cc] + vc.CS && cc + 1 < c_end && vc.clink[cc + 1] != 0) {
+              ++cc;
+              lkacc += vc.clk[cc];
+              smin = fmin(smin, vc.segmin[cc * (TEHMM_SPEC_MAXT + 1)] + lkacc);
+              if (vc.ntie[cc] > 0) {
+                target = vc.t0[cc] + vc.ties[cc * TEHMM_SPEC_MAXT];
+                trow = vc.tierows + (cc * TEHMM_SPEC_MAXT) * NT;
+              } else {
+                target = vc.t0[cc] + vc.CS;
+                trow = vc.rows + ((cc * (vc.CS / TEHMM_VROW)) + (vc.CS / TEHMM_VROW - 1)) * NT;
+              }
+            }
+          }
           if (pg >= CPB || g >= ct0 + vc.CS || target <= cur + CPB) spec = false;
         }
         double wrow = 0.0, wend = 0.0, delta = 0.0;
         bool jump = false;
         if (spec) {
           wrow = vc.rows[((c * (vc.CS / TEHMM_VROW)) + (g - ct0) / TEHMM_VROW) * NT + jl];
-          wend = trow[jl];
+          wend = trow[jl] + lkacc;        // exact: multiples of u inside one binade
         } else {
           if (lane == 0) { seqpos[(it + 1) & 3] = cur + np; *gen = it + 1; }
         }
