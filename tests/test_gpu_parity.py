@@ -286,6 +286,7 @@ CHUNK_CONFIGS = [
     {"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "64"},                        # + lane = item exact Viterbi
     {"TEHMM_SPEC_CHUNK": "512", "TEHMM_LANE_SUB": "256", "TEHMM_LANE_MFMA": "1"},
     {"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "128", "TEHMM_LANE_WARMUP": "24", "TEHMM_FB_RUNS": "0"},
+    {"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "64", "TEHMM_VIT_RUNS": "0"},   # one verification per chunk
 ]
 
 
@@ -298,7 +299,7 @@ def test_chunk_parallel_sparse_model(hip, monkeypatch, cfg):
     from tehmm_amd.engine import HipBatch, HipModel
     from oracle import oracle
     for k in ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_LANE_VIT", "TEHMM_LANE_P0",
-              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS"):
+              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS", "TEHMM_VIT_RUNS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in CHUNK_CONFIGS[cfg].items():
         monkeypatch.setenv(k, v)
@@ -328,7 +329,7 @@ def test_chunk_parallel_deep_emission_drops(hip, monkeypatch, cfg):
     from tehmm_amd.engine import HipBatch, HipModel
     from oracle import oracle
     for k in ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_LANE_VIT", "TEHMM_LANE_P0",
-              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS"):
+              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS", "TEHMM_VIT_RUNS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in CHUNK_CONFIGS[cfg].items():
         monkeypatch.setenv(k, v)
@@ -360,7 +361,7 @@ def test_chunk_parallel_paths(hip, monkeypatch, cfg, N):
     from tehmm_amd.engine import HipBatch, HipModel
     from oracle import oracle
     for k in ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_LANE_VIT", "TEHMM_LANE_P0",
-              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS"):
+              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS", "TEHMM_VIT_RUNS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in CHUNK_CONFIGS[cfg].items():
         monkeypatch.setenv(k, v)
@@ -400,7 +401,7 @@ def test_config_sizes_chunk_parallel_vs_sequential(hip, monkeypatch):
     from tehmm_amd import synth
     from tehmm_amd.engine import HipBatch, HipModel
     for k in ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_LANE_VIT", "TEHMM_LANE_P0",
-              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS"):
+              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS", "TEHMM_VIT_RUNS"):
         monkeypatch.delenv(k, raising=False)
     model = synth.make_model(35, synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=0)
     rs = np.random.RandomState(123)
@@ -447,7 +448,7 @@ def test_chunk_parallel_call_sequences(hip, monkeypatch):
     from tehmm_amd.engine import HipBatch, HipModel
     from oracle import oracle
     for k in ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_LANE_VIT", "TEHMM_LANE_P0",
-              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS"):
+              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS", "TEHMM_VIT_RUNS"):
         monkeypatch.delenv(k, raising=False)
     model = synth.make_model(35, seed=9)
     lens = [3000, 26000, 50000]
