@@ -661,7 +661,7 @@ static void launch_fb_coop(tehmm_batch *b, const tehmm_model *m, const IntervalT
 // ---- speculative chunk-parallel exact Viterbi (no segment ratios) ----------------------------
 static int spec_chunk_size() {
   const char *s = std::getenv("TEHMM_SPEC_CHUNK");     // 0 disables; tests use small chunks
-  int cs = s ? std::atoi(s) : 4096;
+  int cs = s ? std::atoi(s) : 1024;
   if (cs <= 0) return 0;
   return std::max(64, (cs + 63) & ~63);
 }
@@ -977,7 +977,7 @@ static void launch_fb_lane(tehmm_batch *b, const tehmm_model *m, const IntervalT
   hipLaunchKernelGGL((k_fb_stitch<NT>), dim3((fc.n + 3) / 4), dim3(256), 0, st, iv, lg, fc, m->N, lw.pre_f.p,
                      lw.end_f.p, lw.slog32.p, lw.pre_b.p, lw.end_b.p, lw.ok_f.p, lw.ok_b.p);
   const char *er = std::getenv("TEHMM_FB_RUNS");
-  hipLaunchKernelGGL(k_fb_runs, dim3((b->n + 63) / 64), dim3(64), 0, st, iv, fc, (const int *)lw.ok_f.p,
+  hipLaunchKernelGGL(k_fb_runs, dim3(std::max(1, b->n)), dim3(64), 0, st, iv, fc, (const int *)lw.ok_f.p,
                      (const int *)lw.ok_b.p, (er && std::atoi(er) == 0) ? 0 : 1);
 }
 

@@ -473,27 +473,48 @@ __global__ __launch_bounds__(256) void k_fb_stitch(IntervalTab iv, LaneGeom lg, 
 // Runs of linked chunks, one thread per interval: a verified jump of the fix-up chain carries on over
 // every following chunk whose links hold (forward: towards the interval end; backward: towards its
 // start), so a long interval costs its first chunk plus one verification, not one per chunk.
-__global__ void k_fb_runs(IntervalTab iv, FbChunks fc, const int *ok_f, const int *ok_b, int extend) {
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64) void k_fb_runs(IntervalTab iv, FbChunks fc, const int *ok_f, const int *ok_b,
+                                                int extend) {
+  // one wave per interval, 64 chunks per round: run ends / starts from ballots of the "run breaks here"
+  // flags, the log-scale prefix sums from a wave scan
+  const int id = blockIdx.x;
+  const int lane = threadIdx.x;
   if (id >= iv.n) return;
   const int64_t c0 = fc.first[id], c1 = fc.first[id + 1];
-  double acc = 0.0;
-  for (int64_t c = c0; c < c1; ++c) {
-    acc += fc.link_f[c] ? fc.glog_f[c] : 0.0;
-    fc.pre_f[c] = acc;
+  // forward prefix sums of glog_f over the chunks that continue their predecessor
+  double carry = 0.0;
+  for (int64_t b0 = c0; b0 < c1; b0 += 64) {
+    const int64_t c = b0 + lane;
+    double x = (c < c1 && fc.link_f[c]) ? fc.glog_f[c] : 0.0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double y = __shfl_up(x, o);
+      if (lane >= o) x += y;
+    }
+    x += carry;
+    if (c < c1) fc.pre_f[c] = x;
+    carry = __shfl(x, 63);
   }
-  int run = (int)(c1 - 1);
-  for (int64_t c = c1 - 1; c >= c0; --c) {
-    // chunk c + 1 continues chunk c iff its own links hold and its first item continues c's last one
-    const bool cont = extend != 0 && c + 1 < c1 && ok_f[c + 1] != 0 && fc.link_f[c + 1] != 0;
-    if (!cont) run = (int)c;
-    fc.runend_f[c] = run;
+  // runend_f[c] = first chunk >= c after which the forward run breaks (descending over the rounds)
+  int run_carry = (int)(c1 - 1);
+  for (int64_t b0 = c0 + ((c1 - c0 - 1) / 64) * 64; b0 >= c0; b0 -= 64) {
+    const int64_t c = b0 + lane;
+    const bool brk = c >= c1 - 1 || !(extend && ok_f[c + 1] != 0 && fc.link_f[c + 1] != 0);
+    const unsigned long long m = __ballot(brk && c < c1) & (~0ull << lane);
+    const int r = m ? (int)(b0 + __ffsll((long long)m) - 1) : run_carry;
+    if (c < c1) fc.runend_f[c] = r;
+    run_carry = __shfl(r, 0);
   }
-  run = (int)c0;
-  for (int64_t c = c0; c < c1; ++c) {
-    const bool cont = extend != 0 && c > c0 && ok_b[c - 1] != 0 && fc.link_b[c - 1] != 0;
-    if (!cont) run = (int)c;
-    fc.runstart_b[c] = run;
+  // runstart_b[c] = last chunk <= c before which the backward run breaks (ascending)
+  run_carry = (int)c0;
+  for (int64_t b0 = c0; b0 < c1; b0 += 64) {
+    const int64_t c = b0 + lane;
+    const bool brk = c <= c0 || !(extend && c < c1 && ok_b[c - 1] != 0 && fc.link_b[c - 1] != 0);
+    const unsigned long long m = __ballot(brk && c < c1) & (lane == 63 ? ~0ull : ((2ull << lane) - 1));
+    const int r = m ? (int)(b0 + 63 - __clzll((long long)m)) : run_carry;
+    if (c < c1) fc.runstart_b[c] = r;
+    const int last = (int)min((int64_t)63, c1 - 1 - b0);
+    run_carry = __shfl(r, last);
   }
 }
 
