@@ -943,59 +943,61 @@ static void launch_gain_lane(tehmm_batch *b, const tehmm_model *m, const Interva
                      CS, Wu, (const float *)m->ltP.p, (const float *)lw.B32.p, lw.vgain.p);
 }
 
+// Forward lane pass -> [forward links, runs, forward fix-up chain on the side stream]  ||  backward lane pass ->
+// backward links, runs, backward fix-up chain; joined before the combine.  ev_mid is recorded between the
+// lane passes and the backward fix-up chain (stage timing).
 template <int NT>
-static void launch_fb_lane(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const FbChunks &fc,
-                           int Wu, hipStream_t st) {
+static void launch_fb_lane(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em_in,
+                           const FbChunks &fc, int Wu, hipStream_t st, hipEvent_t ev_mid) {
   LaneWork &lw = b->lw;
   const LaneGeom lg = lane_geom(lw);
   const dim3 grid((lw.n_groups + 3) / 4);
-  // TEHMM_LANE_MFMA: 0 = both passes in the VALU form (default), 1 = both on the fp64 matrix cores,
-  // 2 = forward on the matrix cores and backward in the VALU form, concurrently on two streams
-  const char *mfs = std::getenv("TEHMM_LANE_MFMA");
-  const int mf = mfs ? std::atoi(mfs) : 0;
   const dim3 gridm((unsigned)lw.n_groups);           // 4 tiles of 16 items per 256-thread block = one group
-  if (mf == 2) {
-    (void)hipEventRecord(b->evX[0], st);
-    (void)hipStreamWaitEvent(b->sB, b->evX[0], 0);
-    hipLaunchKernelGGL((k_fb_mfma<NT, 0>), gridm, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->A.p, lw.BH.p,
-                       lw.MS.p, lw.AL.p, lw.pre_f.p, lw.end_f.p, lw.slog32.p);
-    hipLaunchKernelGGL((k_fb_lane<NT, 1>), grid, dim3(256), 0, b->sB, iv, lg, m->N, fc.CS, Wu, m->ATG.p, lw.BH.p,
-                       lw.MS.p, lw.BE.p, lw.pre_b.p, lw.end_b.p, (double *)nullptr);
-    (void)hipEventRecord(b->evX[1], b->sB);
-    (void)hipStreamWaitEvent(st, b->evX[1], 0);
-  } else if (mf == 1) {
-    hipLaunchKernelGGL((k_fb_mfma<NT, 0>), gridm, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->A.p, lw.BH.p,
-                       lw.MS.p, lw.AL.p, lw.pre_f.p, lw.end_f.p, lw.slog32.p);
-    hipLaunchKernelGGL((k_fb_mfma<NT, 1>), gridm, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->A.p, lw.BH.p,
-                       lw.MS.p, lw.BE.p, lw.pre_b.p, lw.end_b.p, (double *)nullptr);
-  } else {
-    hipLaunchKernelGGL((k_fb_lane<NT, 0>), grid, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->AG.p, lw.BH.p,
-                       lw.MS.p, lw.AL.p, lw.pre_f.p, lw.end_f.p, lw.slog32.p);
-    hipLaunchKernelGGL((k_fb_lane<NT, 1>), grid, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->ATG.p, lw.BH.p,
-                       lw.MS.p, lw.BE.p, lw.pre_b.p, lw.end_b.p, (double *)nullptr);
-  }
-  hipLaunchKernelGGL((k_fb_stitch<NT>), dim3((fc.n + 3) / 4), dim3(256), 0, st, iv, lg, fc, m->N, lw.pre_f.p,
-                     lw.end_f.p, lw.slog32.p, lw.pre_b.p, lw.end_b.p, lw.ok_f.p, lw.ok_b.p);
+  const dim3 gridc((fc.n + 3) / 4);
+  const dim3 gridi(std::max(1, b->n));
+  // TEHMM_LANE_MFMA: 0 = the VALU form (default), 1 = the fp64 matrix-core form
+  const char *mfs = std::getenv("TEHMM_LANE_MFMA");
+  const bool mf = mfs && std::atoi(mfs) != 0;
   const char *er = std::getenv("TEHMM_FB_RUNS");
-  hipLaunchKernelGGL(k_fb_runs, dim3(std::max(1, b->n)), dim3(64), 0, st, iv, fc, (const int *)lw.ok_f.p,
-                     (const int *)lw.ok_b.p, (er && std::atoi(er) == 0) ? 0 : 1);
-}
-
-template <int NT>
-static void launch_fb_fix_lane(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em_in,
-                               const FbChunks &fc, hipStream_t sF, hipStream_t sBk) {
-  LaneWork &lw = b->lw;
-  const LaneGeom lg = lane_geom(lw);
+  const int extend = (er && std::atoi(er) == 0) ? 0 : 1;
   const EmisTab em = b->n > 256 ? without_lds_tables(em_in) : em_in;
   size_t lds = ((size_t)2 * 64 * (NT + 1) + 2 * 64 + NT + (size_t)em.lds_rows * NT + 8) * sizeof(double);
   allow_lds(k_fb_fix<NT, 0, false, true>, lds);
   allow_lds(k_fb_fix<NT, 1, false, true>, lds);
-  hipLaunchKernelGGL((k_fb_fix<NT, 0, false, true>), dim3(b->n), dim3(128), lds, sF, iv, em, fc, m->N, m->A.p,
+  hipStream_t sS = b->sB;
+  // ---- forward
+  if (mf)
+    hipLaunchKernelGGL((k_fb_mfma<NT, 0>), gridm, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->A.p, lw.BH.p,
+                       lw.MS.p, lw.AL.p, lw.pre_f.p, lw.end_f.p, lw.slog32.p);
+  else
+    hipLaunchKernelGGL((k_fb_lane<NT, 0>), grid, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->AG.p, lw.BH.p,
+                       lw.MS.p, lw.AL.p, lw.pre_f.p, lw.end_f.p, lw.slog32.p);
+  (void)hipEventRecord(b->evX[0], st);
+  (void)hipStreamWaitEvent(sS, b->evX[0], 0);
+  hipLaunchKernelGGL((k_fb_stitch<NT>), gridc, dim3(256), 0, sS, iv, lg, fc, m->N, lw.pre_f.p, lw.end_f.p,
+                     lw.slog32.p, lw.pre_b.p, lw.end_b.p, lw.ok_f.p, lw.ok_b.p, 1);
+  hipLaunchKernelGGL(k_fb_runs, gridi, dim3(64), 0, sS, iv, fc, (const int *)lw.ok_f.p, (const int *)lw.ok_b.p,
+                     extend, 1);
+  hipLaunchKernelGGL((k_fb_fix<NT, 0, false, true>), dim3(b->n), dim3(128), lds, sS, iv, em, fc, m->N, m->A.p,
                      m->lt.p, m->pi.p, (const double *)nullptr, lw.AL.p, b->fwd_lp.p, b->dead.p,
                      (double *)nullptr, (int *)nullptr, 1, b->sw.stats.p, lg, (const int *)lw.ok_f.p);
-  hipLaunchKernelGGL((k_fb_fix<NT, 1, false, true>), dim3(b->n), dim3(128), lds, sBk, iv, em, fc, m->N, m->A.p,
+  (void)hipEventRecord(b->evX[1], sS);
+  // ---- backward
+  if (mf)
+    hipLaunchKernelGGL((k_fb_mfma<NT, 1>), gridm, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->A.p, lw.BH.p,
+                       lw.MS.p, lw.BE.p, lw.pre_b.p, lw.end_b.p, (double *)nullptr);
+  else
+    hipLaunchKernelGGL((k_fb_lane<NT, 1>), grid, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->ATG.p, lw.BH.p,
+                       lw.MS.p, lw.BE.p, lw.pre_b.p, lw.end_b.p, (double *)nullptr);
+  hipLaunchKernelGGL((k_fb_stitch<NT>), gridc, dim3(256), 0, st, iv, lg, fc, m->N, lw.pre_f.p, lw.end_f.p,
+                     lw.slog32.p, lw.pre_b.p, lw.end_b.p, lw.ok_f.p, lw.ok_b.p, 2);
+  hipLaunchKernelGGL(k_fb_runs, gridi, dim3(64), 0, st, iv, fc, (const int *)lw.ok_f.p, (const int *)lw.ok_b.p,
+                     extend, 2);
+  (void)hipEventRecord(ev_mid, st);
+  hipLaunchKernelGGL((k_fb_fix<NT, 1, false, true>), dim3(b->n), dim3(128), lds, st, iv, em, fc, m->N, m->A.p,
                      m->lt.p, m->pi.p, (const double *)nullptr, lw.BE.p, b->fwd_lp.p, b->dead.p,
                      (double *)nullptr, (int *)nullptr, 1, b->sw.stats.p, lg, (const int *)lw.ok_b.p);
+  (void)hipStreamWaitEvent(st, b->evX[1], 0);
 }
 
 template <int NT>
@@ -1176,16 +1178,9 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       fc.pre_f = lw.cpre_f.p; fc.runstart_b = lw.runstart_b.p;
       (void)hipMemsetAsync(b->dead.p, 0, (size_t)(b->n + 1) * sizeof(int), st);
       (void)hipMemsetAsync(sw.stats.p + 2, 0, 4 * sizeof(int), st);
-#define CALL(NT_) launch_fb_lane<NT_>(b, m, iv, fc, WuF, st)
+#define CALL(NT_) launch_fb_lane<NT_>(b, m, iv, em, fc, WuF, st, b->ev[eP + 3])
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
-      (void)hipEventRecord(b->ev[eP + 3], st);
-      (void)hipStreamWaitEvent(b->sB, b->ev[eP + 3], 0);
-#define CALL(NT_) launch_fb_fix_lane<NT_>(b, m, iv, em, fc, st, b->sB)
-      TEHMM_NT_DISPATCH(m->NP, CALL)
-#undef CALL
-      (void)hipEventRecord(b->evX[1], b->sB);
-      (void)hipStreamWaitEvent(st, b->evX[1], 0);
       (void)hipEventRecord(b->ev[eP + 1], st);
 #define CALL(NT_) launch_combine_lane<NT_>(b, m, iv, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)

@@ -398,7 +398,7 @@ template <int NT>
 __global__ __launch_bounds__(256) void k_fb_stitch(IntervalTab iv, LaneGeom lg, FbChunks fc, int N,
                                                    const double *pre_f, const double *end_f,
                                                    const double *slog32, const double *pre_b,
-                                                   const double *end_b, int *ok_f, int *ok_b) {
+                                                   const double *end_b, int *ok_f, int *ok_b, int mode) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= fc.n) return;
@@ -413,8 +413,11 @@ __global__ __launch_bounds__(256) void k_fb_stitch(IntervalTab iv, LaneGeom lg, 
   auto at = [&](const double *p, int64_t item) {
     return live ? p[((((item >> 6) * NT) + jl) << 6) + (item & 63)] : 0.0;
   };
+  // mode: 1 = forward tables only, 2 = backward only, 3 = both (the forward half can run, with the forward
+  // fix-up chain behind it, while the backward lane pass is still at work)
   bool okf = full && c != fc.first[id];
-  if (okf) {
+  if (!(mode & 1)) {
+  } else if (okf) {
     double off = 0.0;
     for (int k = 0; k < SUB; ++k) {
       const int64_t item = item0 + k;
@@ -445,7 +448,8 @@ __global__ __launch_bounds__(256) void k_fb_stitch(IntervalTab iv, LaneGeom lg, 
     fc.glog_f[c] = 0.0;
   }
   bool okb = full && ct0 + fc.CS < T;
-  if (okb) {
+  if (!(mode & 2)) {
+  } else if (okb) {
     for (int k = SUB - 2; k >= 0; --k) {
       double rho;
       const double d = proj_dist(at(pre_b, item0 + k), at(end_b, item0 + k + 1), live, rho);
@@ -465,8 +469,8 @@ __global__ __launch_bounds__(256) void k_fb_stitch(IntervalTab iv, LaneGeom lg, 
     fc.link_b[c] = 0;
   }
   if (lane == 0) {
-    ok_f[c] = okf ? 1 : 0;
-    ok_b[c] = okb ? 1 : 0;
+    if (mode & 1) ok_f[c] = okf ? 1 : 0;
+    if (mode & 2) ok_b[c] = okb ? 1 : 0;
   }
 }
 
@@ -474,7 +478,7 @@ __global__ __launch_bounds__(256) void k_fb_stitch(IntervalTab iv, LaneGeom lg, 
 // every following chunk whose links hold (forward: towards the interval end; backward: towards its
 // start), so a long interval costs its first chunk plus one verification, not one per chunk.
 __global__ __launch_bounds__(64) void k_fb_runs(IntervalTab iv, FbChunks fc, const int *ok_f, const int *ok_b,
-                                                int extend) {
+                                                int extend, int mode) {
   // one wave per interval, 64 chunks per round: run ends / starts from ballots of the "run breaks here"
   // flags, the log-scale prefix sums from a wave scan
   const int id = blockIdx.x;
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(64) void k_fb_runs(IntervalTab iv, FbChunks fc, con
   const int64_t c0 = fc.first[id], c1 = fc.first[id + 1];
   // forward prefix sums of glog_f over the chunks that continue their predecessor
   double carry = 0.0;
-  for (int64_t b0 = c0; b0 < c1; b0 += 64) {
+  for (int64_t b0 = c0; (mode & 1) && b0 < c1; b0 += 64) {
     const int64_t c = b0 + lane;
     double x = (c < c1 && fc.link_f[c]) ? fc.glog_f[c] : 0.0;
 #pragma unroll
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(64) void k_fb_runs(IntervalTab iv, FbChunks fc, con
   }
   // runend_f[c] = first chunk >= c after which the forward run breaks (descending over the rounds)
   int run_carry = (int)(c1 - 1);
-  for (int64_t b0 = c0 + ((c1 - c0 - 1) / 64) * 64; b0 >= c0; b0 -= 64) {
+  for (int64_t b0 = c0 + ((c1 - c0 - 1) / 64) * 64; (mode & 1) && b0 >= c0; b0 -= 64) {
     const int64_t c = b0 + lane;
     const bool brk = c >= c1 - 1 || !(extend && ok_f[c + 1] != 0 && fc.link_f[c + 1] != 0);
     const unsigned long long m = __ballot(brk && c < c1) & (~0ull << lane);
@@ -507,7 +511,7 @@ __global__ __launch_bounds__(64) void k_fb_runs(IntervalTab iv, FbChunks fc, con
   }
   // runstart_b[c] = last chunk <= c before which the backward run breaks (ascending)
   run_carry = (int)c0;
-  for (int64_t b0 = c0; b0 < c1; b0 += 64) {
+  for (int64_t b0 = c0; (mode & 2) && b0 < c1; b0 += 64) {
     const int64_t c = b0 + lane;
     const bool brk = c <= c0 || !(extend && c < c1 && ok_b[c - 1] != 0 && fc.link_b[c - 1] != 0);
     const unsigned long long m = __ballot(brk && c < c1) & (lane == 63 ? ~0ull : ((2ull << lane) - 1));
