@@ -127,7 +127,7 @@ struct LaneWork {
   std::vector<int64_t> h_t0, h_first;
   int64_t h_first_item(int id) const { return h_first[(size_t)id]; }
   DBuf<int> item_iv, ok_f, ok_b, link_f, link_b, runend_f, runstart_b;
-  DBuf<double> glog_f, cpre_f;
+  DBuf<double> glog_f, cpre_f, dl_f, lr_f, dl_b;
   DBuf<int64_t> item_t0, ifirst;
   DBuf<double> B, BH, MS, AL, BE, pre_f, end_f, pre_b, end_b, slog32;
   // Viterbi lane passes
@@ -802,6 +802,9 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
       d->release();
     lw.glog_f.release();
     lw.cpre_f.release();
+    lw.dl_f.release();
+    lw.lr_f.release();
+    lw.dl_b.release();
     lw.B32.release();
     lw.L = L; lw.CS = CS; lw.NP = m->NP;
     lw.n_items = (int)h_iv.size();
@@ -829,6 +832,9 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
       HIPCHK(d->alloc((size_t)std::max(1, b->sw.n_chunks)));
     HIPCHK(lw.glog_f.alloc((size_t)std::max(1, b->sw.n_chunks)));
     HIPCHK(lw.cpre_f.alloc((size_t)std::max(1, b->sw.n_chunks)));
+    HIPCHK(lw.dl_f.alloc((size_t)std::max(1, lw.n_groups) * 64));
+    HIPCHK(lw.lr_f.alloc((size_t)std::max(1, lw.n_groups) * 64));
+    HIPCHK(lw.dl_b.alloc((size_t)std::max(1, lw.n_groups) * 64));
   }
   if (want_fb && !lw.BH.p) {
     HIPCHK(lw.BH.alloc(rows * m->NP));
@@ -953,7 +959,8 @@ static void launch_fb_lane(tehmm_batch *b, const tehmm_model *m, const IntervalT
   const LaneGeom lg = lane_geom(lw);
   const dim3 grid((lw.n_groups + 3) / 4);
   const dim3 gridm((unsigned)lw.n_groups);           // 4 tiles of 16 items per 256-thread block = one group
-  const dim3 gridc((fc.n + 3) / 4);
+  const dim3 gridc((fc.n + 255) / 256);              // one thread per chunk
+  const dim3 gridit((lw.n_items + 255) / 256);       // one thread per item
   const dim3 gridi(std::max(1, b->n));
   // TEHMM_LANE_MFMA: 0 = the VALU form (default), 1 = the fp64 matrix-core form
   const char *mfs = std::getenv("TEHMM_LANE_MFMA");
@@ -974,8 +981,10 @@ static void launch_fb_lane(tehmm_batch *b, const tehmm_model *m, const IntervalT
                        lw.MS.p, lw.AL.p, lw.pre_f.p, lw.end_f.p, lw.slog32.p);
   (void)hipEventRecord(b->evX[0], st);
   (void)hipStreamWaitEvent(sS, b->evX[0], 0);
-  hipLaunchKernelGGL((k_fb_stitch<NT>), gridc, dim3(256), 0, sS, iv, lg, fc, m->N, lw.pre_f.p, lw.end_f.p,
-                     lw.slog32.p, lw.pre_b.p, lw.end_b.p, lw.ok_f.p, lw.ok_b.p, 1);
+  hipLaunchKernelGGL((k_fb_itemlinks<NT>), gridit, dim3(256), 0, sS, lg, m->N, lw.pre_f.p, lw.end_f.p, lw.pre_b.p,
+                     lw.end_b.p, lw.dl_f.p, lw.lr_f.p, lw.dl_b.p, 1);
+  hipLaunchKernelGGL((k_fb_stitch<NT>), gridc, dim3(256), 0, sS, iv, lg, fc, m->N, lw.slog32.p, lw.end_b.p,
+                     lw.dl_f.p, lw.lr_f.p, lw.dl_b.p, lw.ok_f.p, lw.ok_b.p, 1);
   hipLaunchKernelGGL(k_fb_runs, gridi, dim3(64), 0, sS, iv, fc, (const int *)lw.ok_f.p, (const int *)lw.ok_b.p,
                      extend, 1);
   hipLaunchKernelGGL((k_fb_fix<NT, 0, false, true>), dim3(b->n), dim3(128), lds, sS, iv, em, fc, m->N, m->A.p,
@@ -989,8 +998,10 @@ static void launch_fb_lane(tehmm_batch *b, const tehmm_model *m, const IntervalT
   else
     hipLaunchKernelGGL((k_fb_lane<NT, 1>), grid, dim3(256), 0, st, iv, lg, m->N, fc.CS, Wu, m->ATG.p, lw.BH.p,
                        lw.MS.p, lw.BE.p, lw.pre_b.p, lw.end_b.p, (double *)nullptr);
-  hipLaunchKernelGGL((k_fb_stitch<NT>), gridc, dim3(256), 0, st, iv, lg, fc, m->N, lw.pre_f.p, lw.end_f.p,
-                     lw.slog32.p, lw.pre_b.p, lw.end_b.p, lw.ok_f.p, lw.ok_b.p, 2);
+  hipLaunchKernelGGL((k_fb_itemlinks<NT>), gridit, dim3(256), 0, st, lg, m->N, lw.pre_f.p, lw.end_f.p, lw.pre_b.p,
+                     lw.end_b.p, lw.dl_f.p, lw.lr_f.p, lw.dl_b.p, 2);
+  hipLaunchKernelGGL((k_fb_stitch<NT>), gridc, dim3(256), 0, st, iv, lg, fc, m->N, lw.slog32.p, lw.end_b.p,
+                     lw.dl_f.p, lw.lr_f.p, lw.dl_b.p, lw.ok_f.p, lw.ok_b.p, 2);
   hipLaunchKernelGGL(k_fb_runs, gridi, dim3(64), 0, st, iv, fc, (const int *)lw.ok_f.p, (const int *)lw.ok_b.p,
                      extend, 2);
   (void)hipEventRecord(ev_mid, st);

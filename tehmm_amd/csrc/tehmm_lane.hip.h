@@ -389,18 +389,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 // ------------------------------------------------------------------------------------------
-// Links of the forward / backward lane pass, one wave per chunk (lane = state).  A chunk is usable
-// by the fix-up chain when the vectors of consecutive items agree in direction (Hilbert distance
-// <= TEHMM_FB_TOL) at every item boundary inside the chunk.  Forward also lays the items' log-scale
-// records end to end: scale[c][CS/32] in the frame of the chunk's first item.
+// Links of the forward / backward lane pass.  Whether an item had forgotten its (uniform) start by its
+// first official position is CHECKED: its vector after the warm-up against the end vector of its
+// neighbour at the same position (Hilbert distance <= TEHMM_FB_TOL).
+//   k_fb_itemlinks: one THREAD per item, loop over the states -- with lane = item every load of the
+//     item-interleaved vectors is coalesced and the max / min of the ratios need no cross-lane step;
+//     dl_f / lr_f: distance and log(rho) of item i against item i - 1 (forward), dl_b: item i against i + 1.
+//   k_fb_stitch: one thread per chunk: a chunk is usable by the fix-up chain when all links inside it
+//     hold; the items' log-scale records are laid end to end (scale[c][CS/32], frame of the chunk's first
+//     item); link_f / glog_f / link_b connect consecutive chunks for k_fb_runs.
+// mode: 1 = forward tables only, 2 = backward only, 3 = both (the forward half runs, with the forward
+// fix-up chain behind it, while the backward lane pass is still at work).
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void link_accum(double a, double b, bool &bad, double &rmax, double &rmin) {
+  const bool both0 = a == 0.0 && b == 0.0;
+  const bool okl = both0 || (a > 0.0 && b > 0.0 && a < INFINITY && b < INFINITY);
+  bad = bad | !okl;
+  if (okl && !both0) {
+    const double r = a / b;
+    rmax = fmax(rmax, r);
+    rmin = fmin(rmin, r);
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_fb_itemlinks(LaneGeom lg, int N, const double *pre_f, const double *end_f,
+                                                      const double *pre_b, const double *end_b, double *dl_f,
+                                                      double *lr_f, double *dl_b, int mode) {
+  const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= lg.n_items) return;
+  auto vecp = [&](const double *p, int64_t it) { return p + (((it >> 6) * NT) << 6) + (it & 63); };
+  if ((mode & 1) && item >= 1) {
+    const double *a = vecp(pre_f, item), *b = vecp(end_f, item - 1);
+    bool bad = false;
+    double rmax = -1.0, rmin = INFINITY;
+    for (int j = 0; j < N; ++j) link_accum(a[(int64_t)j << 6], b[(int64_t)j << 6], bad, rmax, rmin);
+    const bool ok = !bad && rmax > 0.0 && rmin < INFINITY;
+    dl_f[item] = ok ? rmax / rmin - 1.0 : INFINITY;
+    lr_f[item] = ok ? log(rmax) : 0.0;
+  }
+  if ((mode & 2) && item + 1 < lg.n_items) {
+    const double *a = vecp(pre_b, item), *b = vecp(end_b, item + 1);
+    bool bad = false;
+    double rmax = -1.0, rmin = INFINITY;
+    for (int j = 0; j < N; ++j) link_accum(a[(int64_t)j << 6], b[(int64_t)j << 6], bad, rmax, rmin);
+    const bool ok = !bad && rmax > 0.0 && rmin < INFINITY;
+    dl_b[item] = ok ? rmax / rmin - 1.0 : INFINITY;
+  }
+}
+
 template <int NT>
 __global__ __launch_bounds__(256) void k_fb_stitch(IntervalTab iv, LaneGeom lg, FbChunks fc, int N,
-                                                   const double *pre_f, const double *end_f,
-                                                   const double *slog32, const double *pre_b,
-                                                   const double *end_b, int *ok_f, int *ok_b, int mode) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                   const double *slog32, const double *end_b, const double *dl_f,
+                                                   const double *lr_f, const double *dl_b, int *ok_f, int *ok_b,
+                                                   int mode) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= fc.n) return;
   const int id = fc.iv[c];
   const int64_t T = iv.len[id];
@@ -408,69 +451,43 @@ __global__ __launch_bounds__(256) void k_fb_stitch(IntervalTab iv, LaneGeom lg, 
   const int L = lg.L, SUB = fc.CS / L, R = L / 32;
   const bool full = ct0 + fc.CS <= T;
   const int64_t item0 = lg.ifirst[id] + ct0 / L;
-  const bool live = lane < N;
-  const int jl = min(lane, NT - 1);
-  auto at = [&](const double *p, int64_t item) {
-    return live ? p[((((item >> 6) * NT) + jl) << 6) + (item & 63)] : 0.0;
-  };
-  // mode: 1 = forward tables only, 2 = backward only, 3 = both (the forward half can run, with the forward
-  // fix-up chain behind it, while the backward lane pass is still at work)
-  bool okf = full && c != fc.first[id];
-  if (!(mode & 1)) {
-  } else if (okf) {
-    double off = 0.0;
-    for (int k = 0; k < SUB; ++k) {
-      const int64_t item = item0 + k;
-      if (k > 0) {
-        double rho;
-        const double d = proj_dist(at(pre_f, item), at(end_f, item - 1), live, rho);
-        okf = okf && d <= TEHMM_FB_TOL;
-        off += slog32[(item - 1) * R + R - 1] - log(rho);
-      }
-      for (int m = lane; m < R; m += 64) fc.scale[(int64_t)c * (fc.CS / 32) + k * R + m] = slog32[item * R + m] + off;
-    }
-    // link to the previous chunk (if the lanes ran it): its last item's end vector against this chunk's
-    // first pre vector; glog = log-scale gained over this chunk, expressed in the previous chunk's frame
+  if (mode & 1) {
+    bool okf = full && c != fc.first[id];
     int lf = 0;
     double gl = 0.0;
-    if (okf && c - 1 != fc.first[id]) {
-      double rho;
-      const double d = proj_dist(at(pre_f, item0), at(end_f, item0 - 1), live, rho);
-      lf = d <= TEHMM_FB_TOL ? 1 : 0;
-      gl = off + slog32[(item0 + SUB - 1) * R + R - 1] - log(rho);
+    if (okf) {
+      double off = 0.0;
+      for (int k = 0; k < SUB; ++k) {
+        const int64_t item = item0 + k;
+        if (k > 0) {
+          okf = okf && dl_f[item] <= TEHMM_FB_TOL;
+          off += slog32[(item - 1) * R + R - 1] - lr_f[item];
+        }
+        for (int m = 0; m < R; ++m) fc.scale[(int64_t)c * (fc.CS / 32) + k * R + m] = slog32[item * R + m] + off;
+      }
+      // link to the previous chunk (if the lanes ran it); glog = log-scale gained over this chunk, expressed
+      // in the previous chunk's frame
+      if (okf && c - 1 != fc.first[id]) {
+        lf = dl_f[item0] <= TEHMM_FB_TOL ? 1 : 0;
+        gl = off + slog32[(item0 + SUB - 1) * R + R - 1] - lr_f[item0];
+      }
     }
-    if (lane == 0) {
-      fc.link_f[c] = lf;
-      fc.glog_f[c] = gl;
-    }
-  } else if (lane == 0) {
-    fc.link_f[c] = 0;
-    fc.glog_f[c] = 0.0;
+    fc.link_f[c] = lf;
+    fc.glog_f[c] = gl;
+    ok_f[c] = okf ? 1 : 0;
   }
-  bool okb = full && ct0 + fc.CS < T;
-  if (!(mode & 2)) {
-  } else if (okb) {
-    for (int k = SUB - 2; k >= 0; --k) {
-      double rho;
-      const double d = proj_dist(at(pre_b, item0 + k), at(end_b, item0 + k + 1), live, rho);
-      okb = okb && d <= TEHMM_FB_TOL;
-    }
-    if (lane < NT) fc.wstart[(int64_t)c * NT + lane] = at(end_b, item0);
-    // link to the next chunk (if the lanes ran it for the backward pass)
+  if (mode & 2) {
+    bool okb = full && ct0 + fc.CS < T;
     int lb = 0;
-    const int64_t nt0 = ct0 + fc.CS;
-    if (okb && nt0 + fc.CS < T) {
-      double rho;
-      const double d = proj_dist(at(pre_b, item0 + SUB - 1), at(end_b, item0 + SUB), live, rho);
-      lb = d <= TEHMM_FB_TOL ? 1 : 0;
+    if (okb) {
+      for (int k = SUB - 2; k >= 0; --k) okb = okb && dl_b[item0 + k] <= TEHMM_FB_TOL;
+      const double *w = end_b + (((item0 >> 6) * NT) << 6) + (item0 & 63);
+      for (int j = 0; j < NT; ++j) fc.wstart[(int64_t)c * NT + j] = j < N ? w[(int64_t)j << 6] : 0.0;
+      // link to the next chunk (if the lanes ran it for the backward pass)
+      if (okb && ct0 + 2 * (int64_t)fc.CS < T) lb = dl_b[item0 + SUB - 1] <= TEHMM_FB_TOL ? 1 : 0;
     }
-    if (lane == 0) fc.link_b[c] = lb;
-  } else if (lane == 0) {
-    fc.link_b[c] = 0;
-  }
-  if (lane == 0) {
-    if (mode & 1) ok_f[c] = okf ? 1 : 0;
-    if (mode & 2) ok_b[c] = okb ? 1 : 0;
+    fc.link_b[c] = lb;
+    ok_b[c] = okb ? 1 : 0;
   }
 }
 
