@@ -1,0 +1,73 @@
+"""Randomised parity fuzz of the chunk-parallel evaluation against the CPU oracle (test infrastructure:
+run it from the repo root on a GPU box: python tools/fuzz_chunk_parallel.py [n_cases] [seed0])."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from numpy.testing import assert_array_equal, assert_allclose
+from tehmm_amd import synth
+from tehmm_amd.engine import HipBatch, HipModel
+from oracle import oracle
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+KEYS = ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_LANE_WARMUP_VIT", "TEHMM_LANE_VIT",
+        "TEHMM_LANE_P0", "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS", "TEHMM_VIT_RUNS")
+bad = 0
+t_start = time.time()
+for case in range(n_cases):
+    rs = np.random.RandomState(seed0 + case)
+    for k in KEYS:
+        os.environ.pop(k, None)
+    cs = int(rs.choice([128, 256, 512, 1024]))
+    env = {"TEHMM_SPEC_CHUNK": str(cs)}
+    sub = int(rs.choice([0, 64, 128, 256, 512]))
+    if sub and sub <= cs:
+        env["TEHMM_LANE_SUB"] = str(sub)
+    elif sub == 0:
+        env["TEHMM_LANE_SUB"] = "0"
+    if rs.rand() < 0.3:
+        env["TEHMM_LANE_VIT"] = "0"
+    if rs.rand() < 0.2:
+        env["TEHMM_LANE_MFMA"] = "1"
+    if rs.rand() < 0.2:
+        env["TEHMM_LANE_WARMUP"] = str(int(rs.choice([8, 24, 48])))
+    if rs.rand() < 0.2:
+        env["TEHMM_VIT_RUNS"] = "0"
+    if rs.rand() < 0.2:
+        env["TEHMM_FB_RUNS"] = "0"
+    os.environ.update(env)
+    N = int(rs.choice([2, 3, 5, 8, 13, 20, 27, 35, 36, 41, 50, 63]))
+    K = int(rs.randint(1, 13))
+    syms = [int(rs.choice([1, 2, 3, 5, 17, 100, 255])) for _ in range(K)]
+    gauss = [k for k in range(K) if syms[k] >= 100 and rs.rand() < 0.5]
+    model = synth.make_model(N, syms, gauss, seed=seed0 + case, sparse=float(rs.choice([0.0, 0.0, 0.3, 0.7])))
+    normalize = float(rs.choice([1.0, 1.0, 3.0 / K]))
+    lens = [int(x) for x in rs.choice([1, 7, 64, 300, 1500, 4097, 9000, 20000, 33000], size=int(rs.randint(1, 6)))]
+    if rs.rand() < 0.5:
+        lens.append(int(rs.randint(30000, 70000)))
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = synth.sample_obs(model, int(offs[-1]), seed=case, missing=float(rs.choice([0.0, 0.05, 0.3])))
+    with_ratio = bool(rs.rand() < 0.25)
+    ratios = synth.random_ratios(int(offs[-1]), seed=case) if with_ratio else None
+    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, normalize, model.symbols_per_track)
+    hb = HipBatch(obs, offs, ratios)
+    res = hm.eval(hb, viterbi=True, posterior=True)
+    p_o, vlp_o, flp_o, post_o = oracle.eval_batch(obs, offs, model.log_probs, model.log_startprob,
+                                                  model.log_transmat, normalize, ratios, n_threads=8)
+    try:
+        assert_array_equal(hb.paths(), p_o)
+        assert_array_equal(res["viterbi_logprob"], vlp_o)
+        # (one-symbol models have log P = 0 exactly: compare those absolutely, 1e-13 per position)
+        assert_allclose(res["forward_logprob"], flp_o, rtol=1e-6, atol=1e-9 + 1e-13 * float(offs[-1]))
+        assert_allclose(hb.posteriors(), post_o, rtol=1e-6, atol=1e-15)
+        status = "ok"
+    except AssertionError as e:
+        bad += 1
+        status = "MISMATCH " + str(e).splitlines()[0][:80]
+    t = hb.timing()
+    print(case, status, "N", N, "K", K, "T", int(offs[-1]), env, "ratio" if with_ratio else "",
+          {k.split(":")[1]: int(v) for k, v in t.items() if k.startswith("count:")}, flush=True)
+    hb.close()
+    hm.close()
+print("cases", n_cases, "mismatches", bad, "%.0f s" % (time.time() - t_start))
+sys.exit(1 if bad else 0)
