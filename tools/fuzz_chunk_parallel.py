@@ -10,6 +10,7 @@ from oracle import oracle
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+long_mode = len(sys.argv) > 3 and sys.argv[3] == "long"     # few long intervals: several binades per interval
 KEYS = ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_LANE_WARMUP_VIT", "TEHMM_LANE_VIT",
         "TEHMM_LANE_P0", "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS", "TEHMM_VIT_RUNS")
 bad = 0
@@ -18,7 +19,7 @@ for case in range(n_cases):
     rs = np.random.RandomState(seed0 + case)
     for k in KEYS:
         os.environ.pop(k, None)
-    cs = int(rs.choice([128, 256, 512, 1024]))
+    cs = int(rs.choice([512, 1024, 2048, 4096] if long_mode else [128, 256, 512, 1024]))
     env = {"TEHMM_SPEC_CHUNK": str(cs)}
     sub = int(rs.choice([0, 64, 128, 256, 512]))
     if sub and sub <= cs:
@@ -45,6 +46,10 @@ for case in range(n_cases):
     lens = [int(x) for x in rs.choice([1, 7, 64, 300, 1500, 4097, 9000, 20000, 33000], size=int(rs.randint(1, 6)))]
     if rs.rand() < 0.5:
         lens.append(int(rs.randint(30000, 70000)))
+    if long_mode:
+        lens = [int(rs.randint(100000, 500000)) for _ in range(int(rs.randint(1, 4)))]
+        N = int(rs.choice([5, 8, 20, 35, 36]))
+        model = synth.make_model(N, syms, gauss, seed=seed0 + case, sparse=float(rs.choice([0.0, 0.0, 0.3])))
     offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     obs = synth.sample_obs(model, int(offs[-1]), seed=case, missing=float(rs.choice([0.0, 0.05, 0.3])))
     with_ratio = bool(rs.rand() < 0.25)
