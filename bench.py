@@ -1,18 +1,22 @@
 #!/usr/bin/env python3
 """Headline benchmark: genome positions/sec for Viterbi + posterior (teHmmEval's hot path),
-35 states x 10 tracks, on N MI355X (one process per GPU, intervals sharded, no data-path
-collective: "weak" scaling, every rank evaluates its own 100 Mb shard).
+35 states x 10 tracks, on N MI355X -- one process per GPU, intervals sharded, no data-path
+collective ("weak" scaling: every rank evaluates its own 100 Mb shard).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py [--gpus N] [--steps K] [--warmup W]        # N > 1: starts the N ranks itself
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N ...                  # or under an external launcher
 
 One "step" = one tehmm_eval_batch(VITERBI | POSTERIOR) over the rank's whole batch of intervals,
 observations already resident in HBM, results left in HBM (paths int64 + posteriors f64).
-Rank 0 prints ONE JSON line.
+`--mode estep` times BASELINE config 4 instead (Baum-Welch iterations: fused E-step per rank, ONE
+all-reduce of the packed statistics over RCCL, device M-step).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,6 +27,37 @@ sys.path.insert(0, ROOT)
 
 N_STATES = 35
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F64_VALU_PEAK_TFLOPS = 78.6
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mode", choices=("eval", "estep"), default="eval")
+    ap.add_argument("--mb", type=float, default=None, help="Mb of genome per GPU (eval: 100, estep: 200)")
+    ap.add_argument("--min-kb", type=int, default=200, help="shortest interval (kb)")
+    ap.add_argument("--max-kb", type=int, default=2000, help="longest interval (kb)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the untimed extra measurements (other BASELINE configs, model variants, PCIe)")
+    ap.add_argument("--cpu-sample-kb", type=int, default=250,
+                    help="positions per CPU-baseline interval (kb); 4 intervals per thread")
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`--gpus N` without a launcher around us: start the N ranks as children of THIS process, which has
+    not touched the GPU (never re-exec a process that has), and exit with their code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def gen_obs_torch(model, lens, seed, device):
@@ -57,13 +92,12 @@ def gen_obs_torch(model, lens, seed, device):
     return obs
 
 
-def cpu_baseline(model, n_threads, per_interval, seed=123):
+def cpu_baseline(model, n_threads, per_interval, n_iv, seed=123):
     """Times the CPU oracle (a port of the reference's Cython loops, oracle/tehmm_oracle.c) on a
     bounded sample of the same workload: the teHmmEval flow (score_samples + decode) per interval,
     one interval per worker thread at a time."""
     from oracle import oracle
     from tehmm_amd import synth
-    n_iv = 4 * n_threads
     lens = np.full(n_iv, per_interval, dtype=np.int64)
     offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     obs = synth.sample_obs(model, int(offs[-1]), seed=seed)
@@ -73,35 +107,24 @@ def cpu_baseline(model, n_threads, per_interval, seed=123):
     dt = time.perf_counter() - t0
     return {"value": float(offs[-1]) / dt, "unit": "positions/s", "cores": int(n_threads),
             "kind": "port",
-            "sample": "%d intervals x %d positions, Viterbi + posterior, %d threads, %.1f s"
+            "sample": "%d intervals x %d positions, Viterbi + posterior, %d thread(s), %.1f s"
                       % (n_iv, per_interval, n_threads, dt)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--mb", type=float, default=100.0, help="Mb of genome per GPU")
-    ap.add_argument("--min-kb", type=int, default=200, help="shortest interval (kb)")
-    ap.add_argument("--max-kb", type=int, default=2000, help="longest interval (kb)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true",
-                    help="skip the untimed extra measurement (BASELINE configs[1]: one 10 Mb interval)")
-    ap.add_argument("--cpu-sample-kb", type=int, default=250,
-                    help="positions per CPU-baseline interval (kb); 4 intervals per thread")
-    args = ap.parse_args()
+def time_eval(hm, hb, torch, steps=1, **kw):
+    hm.eval(hb, **kw)                        # warm-up (allocates result buffers / workspaces)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        hm.eval(hb, **kw)
+    return (time.perf_counter() - t1) / steps
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
+def run_eval(args, rank, world, local_rank):
     import torch
     from tehmm_amd import _lib, synth
     from tehmm_amd.engine import HipBatch, HipModel
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     _lib.check(_lib.load().tehmm_set_device(local_rank), "tehmm_set_device")
     device = torch.device("cuda", local_rank)
@@ -110,18 +133,19 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
 
+    mb = 100.0 if args.mb is None else args.mb
     model = synth.make_model(N_STATES, synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=0)
-    total = int(args.mb * 1e6)
+    total = int(mb * 1e6)
     lens = synth.interval_lengths(total, args.min_kb * 1000, args.max_kb * 1000, seed=1000 + rank)
     offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     obs = gen_obs_torch(model, lens, seed=17 + rank, device=device)
     torch.cuda.synchronize()
 
-    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs,
-                  symbols_per_track=model.symbols_per_track)
+    def mk_model(mdl):
+        return HipModel(mdl.log_transmat, mdl.log_startprob, mdl.log_probs,
+                        symbols_per_track=mdl.symbols_per_track)
+    hm = mk_model(model)
     hb = HipBatch(obs.data_ptr(), offs, device_ptrs=True, K=model.n_tracks)
-    del obs
-    torch.cuda.empty_cache()
 
     def barrier():
         if use_dist:
@@ -144,87 +168,285 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # the "trivial gather" of the per-interval scores (north_star): exercised once, outside the timing
+        from tehmm_amd import dist as tdist
+        res = hm.eval(hb, viterbi=True, posterior=False)
+        all_lens = [None] * world
+        dist.all_gather_object(all_lens, [int(x) for x in lens])
+        flat = [x for r in all_lens for x in r]
+        first = sum(len(r) for r in all_lens[:rank])
+        tdist.gather_interval_scalars(np.arange(first, first + len(lens)), res["viterbi_logprob"], len(flat))
 
     if rank == 0:
         K, N = model.n_tracks, model.n_states
         pos_per_step = float(total) * world
         value = pos_per_step * args.steps / dt
+        step_s = dt / args.steps
         kavg = {k: float(np.mean(v)) for k, v in kt.items()}
         dom = max(kavg, key=kavg.get)
-        # algorithmic bytes per position of each stage (API-level I/O only, the
-        # intermediate lattices / emission rows / traceback tables do not count):
-        #   viterbi*: obs in (K) [+ int64 path out (8) where the stage produces it];  forward*: obs in
-        #   (K);  posterior_combine / backward_posterior: posterior row out (8N);  traceback: path out (8)
-        alg = {"viterbi": K + 8, "viterbi_speculate": K, "traceback": 8, "emission_rows": K,
+        # ALGORITHMIC bytes per position of Viterbi + full posterior = K (obs in) + 8 (int64
+        # path out) + 8 N (posterior row out); roofline.achieved = that x the positions one step (one
+        # tehmm_eval_batch launch sequence) processes / the step's duration.
+        alg_pos = K + 8 + 8 * N
+        achieved = alg_pos * float(total) / step_s / 1e9
+        # per-stage view (stage durations are HIP events on the streams the kernels ran on): algorithmic
+        # bytes each stage is responsible for, fp64 operations, measured HBM traffic (rocprofv3 --pmc)
+        alg = {"viterbi": 8, "viterbi_speculate": K, "traceback": 8, "emission_rows": K,
                "forward_backward_speculate": K, "forward_backward": K, "forward": K,
-               "posterior_combine": 8 * N, "backward_posterior": K + 8 * N}
-        # fp64 VALU operations per position of each stage (the resource that actually binds):
-        #   max-plus pass: N*N (add + max);  forward or backward pass: N*N fma = 2 N*N flop
+               "posterior_combine": 8 * N, "backward_posterior": K + 8 * N, "forward_pass": K,
+               "backward_posterior_pass": K + 8 * N}
         flop = {"viterbi_speculate": 2 * 2 * N * N, "viterbi": 2 * N * N, "forward_backward_speculate": 2 * 2 * N * N,
-                "forward_backward": 2 * 2 * N * N, "forward": 2 * N * N, "backward_posterior": 2 * N * N}
-        achieved = alg[dom] * float(total) / (kavg[dom] * 1e-3) / 1e9
+                "forward_backward": 2 * 2 * N * N, "forward": 2 * N * N, "backward_posterior": 2 * N * N,
+                "forward_pass": 2 * N * N, "backward_posterior_pass": 2 * N * N}
         traffic = None
         stage_hbm = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath):     # HBM bytes per position measured with rocprofv3 --pmc (see file)
-            tj = json.load(open(tpath)).get("hbm_bytes_per_position", {})
-            per_pos = tj.get(dom)
-            if per_pos is not None:
-                traffic = per_pos * float(total)
-            # measured HBM bytes (PMC) over the live stage durations: which stages sit on the HBM roof
+        tpath = next((p for p in (os.path.join(ROOT, "profiles", "r02_traffic.json"),
+                                  os.path.join(ROOT, "profiles", "r01_traffic.json")) if os.path.exists(p)), None)
+        if tpath:     # HBM bytes per position measured with rocprofv3 --pmc (see file)
+            tjson = json.load(open(tpath))
+            tj = tjson.get("hbm_bytes_per_position", {})
+            if "total" in tj:
+                traffic = tj["total"] * float(total)
             stage_hbm = {k: tj[k] * float(total) / (kavg[k] * 1e-3) / 1e9 for k in kavg if k in tj}
         out = {
             "metric": "genome positions/sec (Viterbi+posterior), 35 states x 10 tracks",
             "value": value, "unit": "positions/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "warmup": args.warmup, "ms_per_step": step_s * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "teHmmEval Viterbi+posterior, 35 states, 10 tracks (8 multinomial "
                                    "+ 2 gaussian/250 bins), %.0f Mb per GPU in %d intervals of "
                                    "%d-%d kb (config-3 geometry), obs resident in HBM"
-                                   % (args.mb, len(lens), args.min_kb, args.max_kb),
+                                   % (mb, len(lens), args.min_kb, args.max_kb),
                        "positions_per_gpu": total, "intervals_per_gpu": int(len(lens)),
                        "parallelism": "intervals sharded over %d GPU(s), no collective" % world},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "alg_bytes_per_position": alg[dom],
-                         "whole_path_GBps": (K + 8 + 8 * N) * value / world / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "tehmm_eval_batch: Viterbi + posterior over the batch (SURVEY 8d)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "alg_bytes_per_position": alg_pos,
+                         "traffic_source": os.path.basename(tpath) if tpath else None,
+                         "dominant_stage": {"kernel": dom, "ms": kavg[dom],
+                                            "alg_bytes_per_position": alg.get(dom),
+                                            "achieved": alg.get(dom, 0) * float(total) / (kavg[dom] * 1e-3) / 1e9},
                          "stage_hbm_traffic_GBps": stage_hbm,
-                         # the stage that sits highest on the HBM roof (measured bytes / live duration)
-                         "busiest_hbm_stage": (lambda k: {"kernel": k, "achieved": stage_hbm[k], "unit": "GB/s",
-                                                          "frac": stage_hbm[k] / HBM_PEAK_GBPS})(
-                             max(stage_hbm, key=stage_hbm.get)) if stage_hbm else None,
-                         # what binds instead of HBM: fp64 vector issue (78.6 TFLOP/s peak on MI355X)
-                         "valu_f64": {"achieved": flop.get(dom, 0) * float(total) / (kavg[dom] * 1e-3) / 1e12,
-                                      "peak": 78.6, "unit": "TFLOP/s",
-                                      "frac": flop.get(dom, 0) * float(total) / (kavg[dom] * 1e-3) / 1e12 / 78.6}},
+                         # what binds next to HBM: fp64 vector issue (78.6 TFLOP/s peak on MI355X)
+                         "valu_f64": {"achieved": (2 * 3 * N * N) * float(total) / step_s / 1e12,
+                                      "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": (2 * 3 * N * N) * float(total) / step_s / 1e12 / F64_VALU_PEAK_TFLOPS,
+                                      "stage": {k: flop[k] * float(total) / (kavg[k] * 1e-3) / 1e12
+                                                for k in kavg if k in flop}}},
             "kernel_ms": kavg,
         }
         if world == 1 and not args.no_extra:
-            # BASELINE.json configs[1] for orientation (NOT the headline): the same model on ONE
-            # 10 Mb interval -- a single dependent chain, i.e. pure per-step latency.
-            hb.close()
-            one = np.asarray([10_000_000], dtype=np.int64)
-            obs1 = gen_obs_torch(model, one, seed=99, device=device)
-            hb1 = HipBatch(obs1.data_ptr(), np.asarray([0, one[0]], dtype=np.int64), device_ptrs=True,
-                           K=model.n_tracks)
-            hm.eval(hb1, viterbi=True, posterior=True)      # warm-up (allocates the result buffers)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            hm.eval(hb1, viterbi=True, posterior=True)
-            d1 = time.perf_counter() - t1
-            out["extra"] = {"config2_single_10Mb_interval": {
-                "value": float(one[0]) / d1, "unit": "positions/s", "ms": d1 * 1e3,
-                "kernel_ms": hb1.timing()}}
-            hb1.close()
-            del obs1
+            out["extra"] = extras(args, model, hm, hb, obs, offs, lens, device, torch, mk_model)
         if world == 1 and not args.no_cpu_baseline:
             nthr = max(1, min(16, os.cpu_count() or 1))
-            out["cpu_baseline"] = cpu_baseline(model, nthr, args.cpu_sample_kb * 1000)
+            cb = cpu_baseline(model, nthr, args.cpu_sample_kb * 1000, 4 * nthr)
+            cb["one_core"] = cpu_baseline(model, 1, args.cpu_sample_kb * 1000, 2)
+            cb["gpu_over_cpu_all_cores"] = value / cb["value"]
+            out["cpu_baseline"] = cb
         print(json.dumps(out))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def extras(args, model, hm, hb, obs, offs, lens, device, torch, mk_model):
+    """Untimed measurements next to the headline: the same library on the other shapes BASELINE.json and
+    SURVEY 8(d) name, so that the speculation's weak spots and the PCIe-inclusive rate are on the record."""
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch
+    ex = {}
+    K = model.n_tracks
+    total = int(offs[-1])
+
+    def rate(n, s, **kw):
+        d = dict(value=float(n) / s, unit="positions/s", ms=s * 1e3)
+        d.update(kw)
+        return d
+
+    # (1) end to end over PCIe on a 20 Mb slice: H2D of the observations + evaluation + D2H of the paths and
+    #     (a) the full posteriors, (b) the masked posterior sums teHmmEval actually writes
+    n_e2e = min(total, 20_000_000)
+    cut = int(np.searchsorted(offs, n_e2e, side="right")) - 1
+    if cut >= 1:
+        o2 = offs[:cut + 1]
+        n2 = int(o2[-1])
+        host_obs = obs[:n2].cpu().numpy()
+        mask = (np.arange(model.n_states) % 3 == 0).astype(np.float64)
+        for tag in ("full_posteriors", "masked_sum"):
+            t1 = time.perf_counter()
+            hb2 = HipBatch(host_obs, o2)
+            hm.eval(hb2, viterbi=True, posterior=True)
+            p = hb2.paths()
+            q = hb2.posteriors() if tag == "full_posteriors" else hb2.posterior_masksum(mask)
+            d = time.perf_counter() - t1
+            ex["end_to_end_pcie_" + tag] = rate(n2, d, positions=n2, bytes_d2h=int(p.nbytes + q.nbytes),
+                                                note="first call on a fresh batch: includes workspace allocation")
+            hb2.close()
+            del p, q
+        del host_obs
+    hb.close()
+    torch.cuda.empty_cache()
+
+    # (2) BASELINE configs[1]: the same model on ONE 10 Mb interval -- a single dependent chain
+    one = np.asarray([10_000_000], dtype=np.int64)
+    obs1 = gen_obs_torch(model, one, seed=99, device=device)
+    hb1 = HipBatch(obs1.data_ptr(), np.asarray([0, one[0]], dtype=np.int64), device_ptrs=True, K=K)
+    d1 = time_eval(hm, hb1, torch, viterbi=True, posterior=True)
+    ex["config2_single_10Mb_interval"] = rate(one[0], d1, kernel_ms=hb1.timing())
+    d1v = time_eval(hm, hb1, torch, viterbi=True, posterior=False)
+    ex["config2_single_10Mb_interval_viterbi_only"] = rate(one[0], d1v)
+    hb1.close()
+    del obs1
+
+    # (3) model variants on the bench geometry (30 Mb): sparse transitions (p = 0.5 zeros -> -1e100), sticky
+    #     chain (self-transition 0.995, like trained TE models), decode with segment ratios (--segLen 100)
+    sub = int(np.searchsorted(offs, 30_000_000, side="right")) - 1
+    sub = max(sub, 1)
+    o3 = offs[:sub + 1]
+    n3 = int(o3[-1])
+    for tag, mdl in (("sparse_p0.5", synth.make_model(N_STATES, synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN,
+                                                      seed=0, sparse=0.5)),
+                     ("sticky_0.995", synth.make_model(N_STATES, synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN,
+                                                       seed=0, stay=0.995))):
+        ob = gen_obs_torch(mdl, lens[:sub], seed=31, device=device)
+        hmv = mk_model(mdl)
+        hbv = HipBatch(ob.data_ptr(), o3, device_ptrs=True, K=K)
+        d = time_eval(hmv, hbv, torch, viterbi=True, posterior=True)
+        ex["model_" + tag] = rate(n3, d, positions=n3, kernel_ms=hbv.timing())
+        hbv.close()
+        hmv.close()
+        del ob
+    ob = gen_obs_torch(model, lens[:sub], seed=32, device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(5)
+    seglen = torch.clamp(1 + torch.floor(torch.log1p(-torch.rand(n3, generator=g, device=device, dtype=torch.float64))
+                                         / np.log(1 - 1 / 20.0)), max=100.0)
+    ratios = (seglen / 100.0).contiguous()
+    hbr = HipBatch(ob.data_ptr(), o3, ratios=ratios.data_ptr(), device_ptrs=True, K=K)
+    d = time_eval(hm, hbr, torch, viterbi=True, posterior=True, use_ratios=True)
+    ex["decode_with_segment_ratios"] = rate(n3, d, positions=n3, kernel_ms=hbr.timing())
+    hbr.close()
+    del ob, ratios, seglen
+
+    # (4) BASELINE configs[4] shape: 100 states, 10 tracks, segmented (ratios), 2 Mb in 20 intervals
+    m5 = synth.make_model(100, synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=0)
+    l5 = np.full(20, 100_000, dtype=np.int64)
+    o5 = np.concatenate([[0], np.cumsum(l5)]).astype(np.int64)
+    ob = gen_obs_torch(m5, l5, seed=33, device=device)
+    r5 = torch.full((int(o5[-1]),), 0.2, dtype=torch.float64, device=device)
+    hm5 = mk_model(m5)
+    hb5 = HipBatch(ob.data_ptr(), o5, ratios=r5.data_ptr(), device_ptrs=True, K=K)
+    d = time_eval(hm5, hb5, torch, viterbi=True, posterior=True, use_ratios=True)
+    ex["config5_100_states_segmented"] = rate(int(o5[-1]), d, positions=int(o5[-1]))
+    hb5.close()
+    hm5.close()
+    del ob, r5
+
+    # (5) BASELINE configs[3] shape on one GPU: Baum-Welch iterations, 35 states, 12 tracks, 100 kb chunks
+    ex["config4_em_iteration"] = em_iterations(50.0, 2, device, torch, None)
+    return ex
+
+
+def em_iterations(mb, n_iter, device, torch, dist):
+    """Baum-Welch iterations on the config-4 shape: per iteration one fused E-step over the rank's 100 kb
+    chunks (statistics left on the device), ONE all-reduce of the flat statistics buffer, device M-step."""
+    from tehmm_amd import synth
+    from tehmm_amd.engine import DeviceStats, HipBatch, HipModel
+    m4 = synth.make_model(N_STATES, synth.CONFIG4_SYMBOLS, synth.CONFIG4_GAUSSIAN, seed=0)
+    n_chunks = max(1, int(mb * 1e6) // 100_000)
+    l4 = np.full(n_chunks, 100_000, dtype=np.int64)
+    o4 = np.concatenate([[0], np.cumsum(l4)]).astype(np.int64)
+    ob = gen_obs_torch(m4, l4, seed=41, device=device)
+    # start EM from a perturbed model so that the iterations do real work
+    start = synth.make_model(N_STATES, synth.CONFIG4_SYMBOLS, synth.CONFIG4_GAUSSIAN, seed=7)
+    hm4 = HipModel(start.log_transmat, start.log_startprob, start.log_probs, symbols_per_track=start.symbols_per_track)
+    hb4 = HipBatch(ob.data_ptr(), o4, device_ptrs=True, K=m4.n_tracks)
+    st = DeviceStats(hm4)
+    lps = []
+
+    def one_iteration():
+        st.zero()
+        hm4.estep_device(hb4, False, st)
+        if dist is not None:
+            dist.all_reduce(st.tensor, op=dist.ReduceOp.SUM)
+        lps.append(st.head()[0])
+        hm4.mstep(st, False, True, True, 1.0, 1.0, 0.0, None)
+    one_iteration()                         # warm-up (workspace allocation)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t1 = time.perf_counter()
+    for _ in range(n_iter):
+        one_iteration()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    d = (time.perf_counter() - t1) / n_iter
+    n = int(o4[-1])
+    hb4.close()
+    st.close()
+    hm4.close()
+    del ob
+    return {"value": float(n) / d, "unit": "positions/s per EM iteration", "ms_per_iteration": d * 1e3,
+            "positions": n, "chunks": int(n_chunks), "logprob_per_iteration": lps,
+            "alg_bytes_per_position": m4.n_tracks, "hbm_GBps_algorithmic": m4.n_tracks * float(n) / d / 1e9}
+
+
+def run_estep(args, rank, world, local_rank):
+    import torch
+    from tehmm_amd import _lib
+    torch.cuda.set_device(local_rank)
+    _lib.check(_lib.load().tehmm_set_device(local_rank), "tehmm_set_device")
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
+        dist.init_process_group("nccl", device_id=device)
+    mb = 200.0 if args.mb is None else args.mb
+    r = em_iterations(mb, args.steps, device, torch, dist if use_dist else None)
+    if rank == 0:
+        d = r["ms_per_iteration"] * 1e-3
+        value = r["positions"] * world / d
+        out = {"metric": "genome positions/sec (Baum-Welch EM iteration), 35 states x 12 tracks",
+               "value": value, "unit": "positions/s", "n_gpus": world, "steps": args.steps, "warmup": 1,
+               "ms_per_step": d * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "teHmmTrain E-step + all-reduce + M-step, 35 states, 12 tracks (10 multinomial "
+                                      "+ 2 gaussian), %.0f Mb per GPU in 100 kb chunks (config-4 geometry)" % mb,
+                          "positions_per_gpu": r["positions"], "intervals_per_gpu": r["chunks"],
+                          "parallelism": "chunks sharded over %d GPU(s), one all-reduce of %s per iteration"
+                                         % (world, "the packed statistics")},
+               "roofline": {"bound": "hbm", "kernel": "tehmm_estep_batch_device (SURVEY 8d: K bytes / position)",
+                            "achieved": r["alg_bytes_per_position"] * r["positions"] / d / 1e9,
+                            "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": r["alg_bytes_per_position"] * r["positions"] / d / 1e9 / HBM_PEAK_GBPS,
+                            "traffic": None},
+               "logprob_per_iteration": r["logprob_per_iteration"]}
+        print(json.dumps(out))
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    in_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not in_launcher:
+        sys.exit(launch_ranks(args))         # before anything here has touched the GPU
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.mode == "estep":
+        run_estep(args, rank, world, local_rank)
+    else:
+        run_eval(args, rank, world, local_rank)
 
 
 if __name__ == "__main__":

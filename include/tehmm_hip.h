@@ -33,7 +33,7 @@ extern "C" {
 #define TEHMM_ERR_UNSUPPORTED (-3) /* shape outside what the kernels support (see tehmm_max_states) */
 
 /* ---- library / device ---------------------------------------------------------------------- */
-int tehmm_abi_version(void);                 /* bumps when a signature changes */
+int tehmm_abi_version(void);                 /* bumps when a signature changes or is added (2) */
 const char *tehmm_last_error(void);          /* thread-local message of the last failing call */
 int tehmm_device_count(int *count);          /* hipGetDeviceCount */
 int tehmm_set_device(int device);            /* hipSetDevice; one process per GPU calls this once */
@@ -71,10 +71,29 @@ int tehmm_xi_logsum(int64_t T, int N, const double *fwdlattice, const double *lo
                     const double *bwdlattice, const double *framelogprob, double logprob,
                     const double *segRatios, double *logsum_lneta);
 
-/* _emission.fastAccumulateStats -> _fastAccumulateStatsU8 (_emission.pyx:146-190):
- * obsStats [K][N][S] += ... in place. */
+/* _emission.fastAccumulateStats -> _fastAccumulateStatsU8/U16/32 (_emission.pyx:146-234):
+ * obsStats [K][N][S] += ... in place, in the reference's accumulation order. */
 int tehmm_accumulate_obs_u8(int64_t T, int K, int N, int S, const uint8_t *obs, double *obsStats,
                             const double *posteriors, const double *segRatios);
+int tehmm_accumulate_obs_u16(int64_t T, int K, int N, int S, const uint16_t *obs, double *obsStats,
+                             const double *posteriors, const double *segRatios);
+int tehmm_accumulate_obs_i32(int64_t T, int K, int N, int S, const int32_t *obs, double *obsStats,
+                             const double *posteriors, const double *segRatios);
+
+/* _emission.fastUpdateCounts -> _fastUpdateCountsU8/U16/32 (_emission.pyx:236-332), batched over the
+ * labelled intervals of ONE table (the reference calls it once per overlap, emission.py:307-322):
+ *   for i in 0..n_intervals-1, pos in [starts[i], ends[i]):      (table-relative coordinates)
+ *     obsStats[track][states[i]][obs[pos][track]] += segRatios ? segRatios[pos] : 1.0
+ * in that order (so ratio sums round as in the reference).  obs [T][K], obsStats [K][N][S] in place. */
+int tehmm_update_counts_u8(int64_t T, int K, int N, int S, const uint8_t *obs, int n_intervals,
+                           const int64_t *starts, const int64_t *ends, const int32_t *states,
+                           const double *segRatios, double *obsStats);
+int tehmm_update_counts_u16(int64_t T, int K, int N, int S, const uint16_t *obs, int n_intervals,
+                            const int64_t *starts, const int64_t *ends, const int32_t *states,
+                            const double *segRatios, double *obsStats);
+int tehmm_update_counts_i32(int64_t T, int K, int N, int S, const int32_t *obs, int n_intervals,
+                            const int64_t *starts, const int64_t *ends, const int32_t *states,
+                            const double *segRatios, double *obsStats);
 
 /* ---- fused, device-resident entry points ------------------------------------------------------
  * A model handle keeps the N x N log-transition matrix, start vector and emission tables on the
@@ -121,6 +140,23 @@ int tehmm_batch_get_posteriors(tehmm_batch_t *batch, int64_t row0, int64_t row1,
 /* Device pointers of the same buffers (valid until the batch is destroyed or re-evaluated). */
 int tehmm_batch_device_ptrs(tehmm_batch_t *batch, void **paths_i64, void **posteriors_f64);
 
+/* ---- output reductions: what teHmmEval writes per row (bin/teHmmEval.py:238-275) ----------------
+ * Posterior column of --pd / --pdStates (:270-272): out[r - row0] = sum_j posteriors[r][j] * mask[j]
+ * for rows [row0, row1) of the last evaluation's device-resident posteriors (8 instead of 8 N bytes
+ * per row cross PCIe).  mask [N] and out are host arrays.  (The reference's off-by-one row, quirk
+ * Q15, is the caller's: tehmm_amd/output.py.) */
+int tehmm_batch_posterior_masksum(tehmm_batch_t *batch, const double *mask, int64_t row0, int64_t row1,
+                                  double *out);
+/* BED coordinates of every row of a table (:243-266): segOffsets [n_rows] (NULL: unsegmented),
+ * maskOffsets [n_mask] = TrackTable.getMaskRunningOffsets() (NULL: no mask); starts / ends [n_rows]. */
+int tehmm_bed_coords(int64_t n_rows, int64_t table_start, int64_t table_end, const int64_t *segOffsets,
+                     const int32_t *maskOffsets, int64_t n_mask, int64_t *starts, int64_t *ends);
+/* Host-side writer of the per-row lines "chrom\tstart\tend\tX\n" (:266-275).  X = names[states[i]]
+ * (names NULL: the integer) or, with values != NULL, values[i] as Python 2 prints a float64. */
+int tehmm_write_bed(const char *path, int append, const char *chrom, int64_t n, const int64_t *starts,
+                    const int64_t *ends, const int64_t *states, int n_names, const char *const *names,
+                    const double *values);
+
 /* Baum-Welch E-step over every interval of the batch (basehmm.py:504-523 with
  * MultitrackHmm._accumulate_sufficient_statistics, hmm.py:545-574): accumulates INTO the host
  * arrays start[N], trans[N][N], obsStats[K][N][S] (the caller initialises them, e.g. with
@@ -128,6 +164,55 @@ int tehmm_batch_device_ptrs(tehmm_batch_t *batch, void **paths_i64, void **poste
  * the batch's segRatios everywhere, as fit does for segmented TrackTables. */
 int tehmm_estep_batch(tehmm_model_t *model, tehmm_batch_t *batch, int use_ratios, double *start,
                       double *trans, double *obsStats, double *logprob_sum);
+
+/* ---- device-resident Baum-Welch ----------------------------------------------
+ * The E-step's raw sufficient statistics stay on the device in ONE flat fp64 buffer
+ * (tehmm_model_stats_size doubles: [logprob sum, sequence count, start, transition accumulators,
+ * emission histograms]); buffers of several batches / ranks simply add (one all-reduce per EM
+ * iteration over this buffer, basehmm.py:507-522 summed across shards), and tehmm_model_mstep turns the
+ * sum into the next parameters without leaving the device (MultitrackHmm._do_mstep, hmm.py:576-616;
+ * emission.maximize, emission.py:243-267; gaussian refit, emission.py:502-593, quirk Q19). */
+int64_t tehmm_model_stats_size(const tehmm_model_t *model);
+int tehmm_stats_alloc(const tehmm_model_t *model, double **dev_stats);   /* zero-filled device buffer */
+int tehmm_stats_zero(const tehmm_model_t *model, double *dev_stats);
+int tehmm_stats_free(double *dev_stats);
+int tehmm_stats_head(const double *dev_stats, double *logprob_sum, double *n_sequences);
+/* tehmm_estep_batch with the statistics ADDED into dev_stats (a device pointer: from tehmm_stats_alloc
+ * or e.g. a torch tensor that RCCL will all-reduce). */
+int tehmm_estep_batch_device(tehmm_model_t *model, tehmm_batch_t *batch, int use_ratios, double *dev_stats,
+                             double *logprob_sum);
+/* M-step: updates the model handle in place from the (summed) statistics.  update_*: the 's', 't', 'e'
+ * of the reference's `params`; priors default to 1.0 there; fudge = emission model's fudge
+ * (initStats + maximize); gaussian tracks: indices, the real value of every symbol
+ * (gauss_values [n_gauss][S], CategoryMap.getMapBack) and the uniform mix (0.1); gauss_params
+ * [n_gauss][N][2] (mu, sigma) out, may be NULL. */
+int tehmm_model_mstep(tehmm_model_t *model, const double *dev_stats, int update_start, int update_trans,
+                      int update_emission, double startprob_prior, double transmat_prior, double fudge,
+                      int n_gauss, const int32_t *gauss_tracks, const double *gauss_values, double uniform_mix,
+                      double *gauss_params);
+/* Current parameters of the handle: log_transmat [N][N], log_startprob [N], logProbs [K][N][S] (only
+ * the cells of real symbols are written); any pointer may be NULL. */
+int tehmm_model_get_params(tehmm_model_t *model, double *log_transmat, double *log_startprob, double *logProbs);
+
+/* ---- the step before the path: segment compression and mask compaction --------
+ * TrackTable.segment = interpolateSegments + compressSegments (track.py:449-533, 594-620) for a uint8
+ * table data [T][K] and ascending table-relative segOffsets [n_seg]: out [n_seg][K] holds the mode of
+ * every categorical track over the segment; for gaussian tracks (is_gaussian[k] != 0) means [n_seg][K]
+ * holds the mean of mapback[k][symbol] (mapback [K][256], CategoryMap.getMapBackTable) and out keeps
+ * the segment's first symbol -- the caller maps the mean to a symbol (CategoryMap.getMap(update=True)
+ * may create one, track.py:612-616). */
+int tehmm_segment_table_u8(int64_t T, int K, const uint8_t *data, int64_t n_seg, const int64_t *segOffsets,
+                           const uint8_t *is_gaussian, const double *mapback, uint8_t *out, double *means);
+/* IntegerTrackTable.setMaskTable + getMaskRunningOffsets (track.py:622-662; _track.runSum,
+ * _track.pyx:13-25): keep [T] = 1 where no mask track covers the position, run_full [T] = number of cut
+ * positions before i, out_data [n_keep][K] / run_masked [n_keep] = the kept rows and their offsets. */
+int tehmm_mask_table_u8(int64_t T, int K, const uint8_t *data, int KM, const uint8_t *maskdata, uint8_t *keep,
+                        int32_t *run_full, uint8_t *out_data, int32_t *run_masked, int64_t *n_keep);
+
+/* Forward log-likelihood of every interval from the last tehmm_estep_batch or posterior evaluation
+ * (the per-sequence `lpr` of basehmm.py:513, which MultitrackHmm's best-iteration bookkeeping,
+ * hmm.py:690-711, consumes sequence by sequence); out [n_intervals] host. */
+int tehmm_batch_get_interval_logprobs(tehmm_batch_t *batch, double *out);
 
 /* Per-kernel device time of the last fused call on this batch, measured with HIP events on the
  * streams the kernels ran on.  names[i] is a static string; returns the number of entries

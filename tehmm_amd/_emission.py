@@ -1,5 +1,5 @@
 """Drop-in for the reference's Cython module ``teHmm._emission`` (_emission.pyx): canFast,
-fastAllLogProbs, fastAccumulateStats with the same arguments and in-place semantics, computed by
+fastAllLogProbs, fastAccumulateStats, fastUpdateCounts with the same arguments and in-place semantics, computed by
 libtehmm_hip.so."""
 import ctypes
 
@@ -45,21 +45,60 @@ def fastAllLogProbs(obs, logProbs, outProbs, normalize, segRatios):
     _lib.check(rc, fn)
 
 
+_SUFFIX = {np.dtype(np.uint8): "u8", np.dtype(np.uint16): "u16", np.dtype(np.int32): "i32"}
+
+
 def fastAccumulateStats(obs, obsStats, posteriors, segRatios):
-    """_emission.pyx:146-190: obsStats [K,N,S] += in place."""
+    """_emission.pyx:146-234: obsStats [K,N,S] += in place (uint8 / uint16 / int32 observations)."""
     obs = _table_array(obs)
     assert isinstance(obs, np.ndarray) and obs.ndim == 2
     assert isinstance(obsStats, np.ndarray) and obsStats.dtype == np.float64
     assert obsStats.flags.c_contiguous
-    if obs.dtype != np.uint8:
-        if obs.max(initial=0) > 255 or obs.min(initial=0) < 0:
-            raise ValueError("fastAccumulateStats: symbols above 255 are not supported")
-        obs = obs.astype(np.uint8)
+    sfx = _SUFFIX.get(obs.dtype)
+    assert sfx is not None, obs.dtype            # the reference: "assert False" (_emission.pyx:167)
     obs = np.ascontiguousarray(obs)
     T, K = obs.shape
     _, N, S = obsStats.shape
     post = np.ascontiguousarray(posteriors, dtype=np.float64)
     r = None if segRatios is None else np.ascontiguousarray(segRatios, dtype=np.float64)
-    rc = _lib.load().tehmm_accumulate_obs_u8(T, K, N, S, obs.ctypes.data_as(ctypes.c_void_p),
-                                             ptr(obsStats, f64p), ptr(post, f64p), ptr(r, f64p))
-    _lib.check(rc, "tehmm_accumulate_obs_u8")
+    fn = "tehmm_accumulate_obs_" + sfx
+    rc = getattr(_lib.load(), fn)(T, K, N, S, obs.ctypes.data_as(ctypes.c_void_p),
+                                  ptr(obsStats, f64p), ptr(post, f64p), ptr(r, f64p))
+    _lib.check(rc, fn)
+
+
+def fastUpdateCountsBatch(intervals, trackTable, obsStats, segRatios):
+    """All labelled intervals of ONE table in one device call: intervals = sequence of
+    (chrom, start, end, state) in table-relative coordinates (TrackTable.getOverlapInTableCoords),
+    processed in the given order -- the order emission.supervisedTrain feeds them to
+    fastUpdateCounts one by one (emission.py:307-322)."""
+    from ._lib import i32p, i64p
+    obs = _table_array(trackTable)
+    assert isinstance(obs, np.ndarray) and obs.ndim == 2
+    assert isinstance(obsStats, np.ndarray) and obsStats.dtype == np.float64
+    assert obsStats.flags.c_contiguous
+    sfx = _SUFFIX.get(obs.dtype)
+    assert sfx is not None, obs.dtype
+    obs = np.ascontiguousarray(obs)
+    T, K = obs.shape
+    _, N, S = obsStats.shape
+    n = len(intervals)
+    if n == 0:
+        return
+    starts = np.ascontiguousarray([iv[1] for iv in intervals], dtype=np.int64)
+    ends = np.ascontiguousarray([iv[2] for iv in intervals], dtype=np.int64)
+    states = np.ascontiguousarray([iv[3] for iv in intervals], dtype=np.int32)
+    r = None if segRatios is None else np.ascontiguousarray(segRatios, dtype=np.float64)
+    fn = "tehmm_update_counts_" + sfx
+    rc = getattr(_lib.load(), fn)(T, K, N, S, obs.ctypes.data_as(ctypes.c_void_p), n,
+                                  ptr(starts, i64p), ptr(ends, i64p), ptr(states, i32p),
+                                  ptr(r, f64p), ptr(obsStats, f64p))
+    _lib.check(rc, fn)
+
+
+def fastUpdateCounts(bedInterval, trackTable, obsStats, segRatios):
+    """_emission.pyx:236-332: obsStats[track, state, obs[pos, track]] += 1 (or segRatios[pos]) for
+    pos in [bedInterval[1], bedInterval[2]), state = bedInterval[3]."""
+    from .track import TrackTable
+    assert isinstance(trackTable, TrackTable)
+    fastUpdateCountsBatch([bedInterval], trackTable, obsStats, segRatios)

@@ -34,6 +34,27 @@ SIGNATURES = {
     "tehmm_viterbi": (c_int, [c_i64, c_int, f64p, f64p, f64p, f64p, i64p, f64p]),
     "tehmm_xi_logsum": (c_int, [c_i64, c_int, f64p, f64p, f64p, f64p, c_dbl, f64p, f64p]),
     "tehmm_accumulate_obs_u8": (c_int, [c_i64, c_int, c_int, c_int, vp, f64p, f64p, f64p]),
+    "tehmm_accumulate_obs_u16": (c_int, [c_i64, c_int, c_int, c_int, vp, f64p, f64p, f64p]),
+    "tehmm_accumulate_obs_i32": (c_int, [c_i64, c_int, c_int, c_int, vp, f64p, f64p, f64p]),
+    "tehmm_update_counts_u8": (c_int, [c_i64, c_int, c_int, c_int, vp, c_int, i64p, i64p, i32p, f64p, f64p]),
+    "tehmm_update_counts_u16": (c_int, [c_i64, c_int, c_int, c_int, vp, c_int, i64p, i64p, i32p, f64p, f64p]),
+    "tehmm_update_counts_i32": (c_int, [c_i64, c_int, c_int, c_int, vp, c_int, i64p, i64p, i32p, f64p, f64p]),
+    "tehmm_model_stats_size": (c_i64, [vp]),
+    "tehmm_stats_alloc": (c_int, [vp, ctypes.POINTER(vp)]),
+    "tehmm_stats_zero": (c_int, [vp, vp]),
+    "tehmm_stats_free": (c_int, [vp]),
+    "tehmm_stats_head": (c_int, [vp, f64p, f64p]),
+    "tehmm_estep_batch_device": (c_int, [vp, vp, c_int, vp, f64p]),
+    "tehmm_model_mstep": (c_int, [vp, vp, c_int, c_int, c_int, c_dbl, c_dbl, c_dbl, c_int, i32p, f64p, c_dbl,
+                                  f64p]),
+    "tehmm_model_get_params": (c_int, [vp, f64p, f64p, f64p]),
+    "tehmm_segment_table_u8": (c_int, [c_i64, c_int, u8p, c_i64, i64p, u8p, f64p, u8p, f64p]),
+    "tehmm_mask_table_u8": (c_int, [c_i64, c_int, u8p, c_int, u8p, u8p, i32p, u8p, i32p, i64p]),
+    "tehmm_batch_get_interval_logprobs": (c_int, [vp, f64p]),
+    "tehmm_batch_posterior_masksum": (c_int, [vp, f64p, c_i64, c_i64, f64p]),
+    "tehmm_bed_coords": (c_int, [c_i64, c_i64, c_i64, i64p, i32p, c_i64, i64p, i64p]),
+    "tehmm_write_bed": (c_int, [ctypes.c_char_p, c_int, ctypes.c_char_p, c_i64, i64p, i64p, i64p, c_int,
+                                ctypes.POINTER(ctypes.c_char_p), f64p]),
     "tehmm_model_create": (c_int, [c_int, c_int, c_int, f64p, f64p, f64p, c_dbl, i32p,
                                    ctypes.POINTER(vp)]),
     "tehmm_model_destroy": (c_int, [vp]),

@@ -29,11 +29,16 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in DEPS if os.path.exists(d))
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build(force=False, verbose=False, dev_nt=None):
+    """dev_nt (or TEHMM_DEV_NT in the environment): development build for ONE padded state count
+    (fast to compile; every other N then fails with TEHMM_ERR_UNSUPPORTED-like silence -- never ship it)."""
+    dev_nt = dev_nt or os.environ.get("TEHMM_DEV_NT")
+    if not force and not needs_build() and not dev_nt:
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
            "-std=c++17", "-Wall", "-Wno-unused-function", "-o", LIB] + SOURCES
+    if dev_nt:
+        cmd.insert(1, "-DTEHMM_DEV_NT=%d" % int(dev_nt))
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

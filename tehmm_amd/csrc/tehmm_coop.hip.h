@@ -132,12 +132,13 @@ __device__ __forceinline__ void emis_rows(const EmisTab &e, const double *ltab, 
     for (int bb = 0; bb < 4; ++bb) {
       const int k = 4 * d + bb;
       if (k < e.K) {
-        int sym = (int)((w >> (8 * bb)) & 0xffu);
-        sym = min(sym, e.rowcnt[k] - 1);
+        const int sym = (int)((w >> (8 * bb)) & 0xffu);
+        const bool inr = sym < e.rowcnt[k];       // beyond the track's symbols: the zero padding
         const int lb = e.ldsbase[k];
         if (lb >= 0) {
           lds_cd2 *tr = (lds_cd2 *)(size_t)((unsigned)(size_t)(
-              __attribute__((address_space(3))) const double *)ltab + (unsigned)((lb + sym) * NT * 8));
+              __attribute__((address_space(3))) const double *)ltab +
+              (unsigned)((inr ? lb + sym : e.lds_zero) * NT * 8));
 #pragma unroll
           for (int jj = 0; jj < NT / 2; ++jj) {
             const d2v v = tr[jj];
@@ -145,7 +146,7 @@ __device__ __forceinline__ void emis_rows(const EmisTab &e, const double *ltab, 
             x[2 * jj + 1] += v.y;
           }
         } else {
-          const double2 *tr = (const double2 *)(e.tab + (int64_t)(e.rowbase[k] + sym) * NT);
+          const double2 *tr = (const double2 *)(e.tab + (int64_t)(inr ? e.rowbase[k] + sym : e.zero_row) * NT);
 #pragma unroll
           for (int jj = 0; jj < NT / 2; ++jj) {
             const double2 v = tr[jj];
@@ -684,10 +685,11 @@ __global__ __launch_bounds__(256) void k_estep_accum(IntervalTab iv, EmisTab em,
       const double gr = RATIO ? gam * r : gam;
       const uint32_t *orow = em.obs32 + (p0 + t) * em.KPW;
       for (int k = 0; k < em.K; ++k) {
-        int sym = (int)((orow[k >> 2] >> ((k & 3) * 8)) & 0xffu);
-        sym = min(sym, em.rowcnt[k] - 1);
+        const int sym = (int)((orow[k >> 2] >> ((k & 3) * 8)) & 0xffu);
         const int lb = em.ldsbase[k];
-        if (live) {
+        // (a symbol beyond the track's last one lands in the reference's padding cells, which
+        //  emission.maximize never reads: not booked here)
+        if (live && sym < em.rowcnt[k]) {
           if (lb >= 0) atomicAdd(&lstat[(lb + sym) * NT + lane], gr);
           else atomicAdd(&gstat[(int64_t)(em.rowbase[k] + sym) * NT + lane], gr);
         }

@@ -4,6 +4,7 @@
 #include "tehmm_kernels.hip.h"
 #include "tehmm_coop.hip.h"
 #include "tehmm_lane.hip.h"
+#include "tehmm_aux.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -47,6 +48,7 @@ struct DBuf {
     if (p) (void)hipFree(p);
     p = nullptr;
     n = 0;
+    cap = 0;
   }
   hipError_t alloc(size_t count) {
     release();
@@ -58,6 +60,22 @@ struct DBuf {
     hipError_t e = alloc(count);
     if (e != hipSuccess || count == 0) return e;
     return hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice);
+  }
+  // grow-only capacity (no hipFree / hipMalloc -- i.e. no device-wide synchronisation -- once warm)
+  size_t cap = 0;
+  hipError_t ensure(size_t count) {
+    if (count <= cap && p) { n = count; return hipSuccess; }
+    hipError_t e = alloc(count + count / 4 + 16);
+    cap = e == hipSuccess ? n : 0;
+    n = count;
+    return e;
+  }
+  // Asynchronous fill on a stream; `h` must stay alive until the stream has been synchronised
+  // (the callers keep such staging vectors in the batch).
+  hipError_t fill_async(const T *h, size_t count, hipStream_t st) {
+    hipError_t e = ensure(count);
+    if (e != hipSuccess || count == 0) return e;
+    return hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, st);
   }
 };
 
@@ -95,13 +113,15 @@ struct tehmm_model {
   int rowbase[TEHMM_MAX_TRACKS];
   int rowcnt[TEHMM_MAX_TRACKS];
   int ldsbase[TEHMM_MAX_TRACKS];
-  int lds_rows = 0;
+  int lds_rows = 0, lds_zero = 0;   // LDS-staged rows (incl. one zero row at index lds_zero)
   std::vector<double> h_lt;   // [N][N] host copy (diag etc.)
 };
 
 // workspace of the fused E-step, kept with the batch so that EM iterations reuse it
 struct EstepWork {
-  DBuf<double> alpha, beta, wrows, fwd_lp, C, D, start, stat;
+  DBuf<double> alpha, beta, wrows, fwd_lp;
+  DBuf<double> statbuf;            // raw statistics of the host-array entry point (layout: tehmm_aux.hip.h)
+  double *C = nullptr, *D = nullptr, *start = nullptr, *stat = nullptr;   // views into a statistics buffer
   DBuf<int> escale, dead, order, chunk_iv;
   DBuf<int64_t> grow0, chunk_t0;
   int64_t rows_cap = 0;
@@ -136,6 +156,12 @@ struct LaneWork {
   DBuf<VitChunks> d_vc;       // device copies of the argument tables of k_vit_lane
   DBuf<VitItems> d_vi;
   DBuf<int> vbad, vntie, vties, wk_g, wk_e;
+  // host staging of one evaluation: sources of asynchronous copies, alive until the call has
+  // synchronised its streams
+  std::vector<double> hs_gain, hs_cgain, hs_qt;
+  std::vector<int> hs_e, hs_wkg, hs_wke;
+  VitChunks hs_vc;
+  VitItems hs_vi;
 };
 
 struct tehmm_batch {
@@ -169,6 +195,7 @@ struct tehmm_batch {
   hipEvent_t evX[2] = {nullptr, nullptr};
   hipEvent_t ev[16];
   int n_ev = 0;
+  std::vector<double> h_fwd_lp;   // per-interval forward log-likelihood of the last estep / posterior evaluation
   std::vector<std::string> tnames;
   std::vector<std::pair<int, int>> tpairs;
   std::vector<double> tms;
@@ -176,7 +203,7 @@ struct tehmm_batch {
 
 // All tehmm_* functions below are declared extern "C" in include/tehmm_hip.h.
 
-int tehmm_abi_version(void) { return 1; }
+int tehmm_abi_version(void) { return 2; }
 const char *tehmm_last_error(void) { return g_err.c_str(); }
 int tehmm_max_states(void) { return kMaxStates; }
 
@@ -289,22 +316,76 @@ int tehmm_xi_logsum(int64_t T, int N, const double *fwd, const double *lt, const
   return TEHMM_OK;
 }
 
-int tehmm_accumulate_obs_u8(int64_t T, int K, int N, int S, const uint8_t *obs, double *obsStats,
-                            const double *post, const double *segRatios) {
+template <typename ObsT>
+static int accumulate_impl(int64_t T, int K, int N, int S, const ObsT *obs, double *obsStats,
+                           const double *post, const double *segRatios) {
   if (T < 0 || K <= 0 || N <= 0 || S <= 0 || !obs || !obsStats || !post)
-    return fail(TEHMM_ERR_ARG, "tehmm_accumulate_obs_u8: bad argument");
+    return fail(TEHMM_ERR_ARG, "tehmm_accumulate_obs: bad argument");
   if (T == 0) return TEHMM_OK;
-  DBuf<uint8_t> d_obs;
+  DBuf<ObsT> d_obs;
   DBuf<double> d_st, d_p, d_r;
   HIPCHK(d_obs.upload(obs, (size_t)T * K));
   HIPCHK(d_st.upload(obsStats, (size_t)K * N * S));
   HIPCHK(d_p.upload(post, (size_t)T * N));
   if (segRatios) HIPCHK(d_r.upload(segRatios, (size_t)T));
-  hipLaunchKernelGGL(k_accumulate_obs, dim3(grid_for((int64_t)K * N, 64)), dim3(64), 0, 0, T, K, N,
+  hipLaunchKernelGGL((k_accumulate_obs<ObsT>), dim3(grid_for((int64_t)K * N, 64)), dim3(64), 0, 0, T, K, N,
                      S, d_obs.p, d_st.p, d_p.p, d_r.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(obsStats, d_st.p, (size_t)K * N * S * sizeof(double), hipMemcpyDeviceToHost));
   return TEHMM_OK;
+}
+
+int tehmm_accumulate_obs_u8(int64_t T, int K, int N, int S, const uint8_t *obs, double *obsStats,
+                            const double *post, const double *segRatios) {
+  return accumulate_impl<uint8_t>(T, K, N, S, obs, obsStats, post, segRatios);
+}
+int tehmm_accumulate_obs_u16(int64_t T, int K, int N, int S, const uint16_t *obs, double *obsStats,
+                             const double *post, const double *segRatios) {
+  return accumulate_impl<uint16_t>(T, K, N, S, obs, obsStats, post, segRatios);
+}
+int tehmm_accumulate_obs_i32(int64_t T, int K, int N, int S, const int32_t *obs, double *obsStats,
+                             const double *post, const double *segRatios) {
+  return accumulate_impl<int32_t>(T, K, N, S, obs, obsStats, post, segRatios);
+}
+
+template <typename ObsT>
+static int update_counts_impl(int64_t T, int K, int N, int S, const ObsT *obs, int n_iv,
+                              const int64_t *starts, const int64_t *ends, const int32_t *states,
+                              const double *segRatios, double *obsStats) {
+  if (T < 0 || K <= 0 || N <= 0 || S <= 0 || n_iv < 0 || !obs || !obsStats || (n_iv > 0 && (!starts || !ends || !states)))
+    return fail(TEHMM_ERR_ARG, "tehmm_update_counts: bad argument");
+  for (int i = 0; i < n_iv; ++i)
+    if (starts[i] < 0 || ends[i] > T || states[i] < 0 || states[i] >= N)
+      return fail(TEHMM_ERR_ARG, "tehmm_update_counts: interval outside the table or state >= N");
+  if (T == 0 || n_iv == 0) return TEHMM_OK;
+  DBuf<ObsT> d_obs;
+  DBuf<double> d_st, d_r;
+  DBuf<int64_t> d_s, d_e;
+  DBuf<int32_t> d_q;
+  HIPCHK(d_obs.upload(obs, (size_t)T * K));
+  HIPCHK(d_st.upload(obsStats, (size_t)K * N * S));
+  HIPCHK(d_s.upload(starts, (size_t)n_iv));
+  HIPCHK(d_e.upload(ends, (size_t)n_iv));
+  HIPCHK(d_q.upload(states, (size_t)n_iv));
+  if (segRatios) HIPCHK(d_r.upload(segRatios, (size_t)T));
+  hipLaunchKernelGGL((k_update_counts<ObsT>), dim3(K, N), dim3(std::min(256, (S + 63) & ~63)), 0, 0, n_iv, d_s.p,
+                     d_e.p, d_q.p, K, N, S, d_obs.p, d_st.p, d_r.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(obsStats, d_st.p, (size_t)K * N * S * sizeof(double), hipMemcpyDeviceToHost));
+  return TEHMM_OK;
+}
+
+int tehmm_update_counts_u8(int64_t T, int K, int N, int S, const uint8_t *obs, int n_iv, const int64_t *starts,
+                           const int64_t *ends, const int32_t *states, const double *segRatios, double *obsStats) {
+  return update_counts_impl<uint8_t>(T, K, N, S, obs, n_iv, starts, ends, states, segRatios, obsStats);
+}
+int tehmm_update_counts_u16(int64_t T, int K, int N, int S, const uint16_t *obs, int n_iv, const int64_t *starts,
+                            const int64_t *ends, const int32_t *states, const double *segRatios, double *obsStats) {
+  return update_counts_impl<uint16_t>(T, K, N, S, obs, n_iv, starts, ends, states, segRatios, obsStats);
+}
+int tehmm_update_counts_i32(int64_t T, int K, int N, int S, const int32_t *obs, int n_iv, const int64_t *starts,
+                            const int64_t *ends, const int32_t *states, const double *segRatios, double *obsStats) {
+  return update_counts_impl<int32_t>(T, K, N, S, obs, n_iv, starts, ends, states, segRatios, obsStats);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -353,7 +434,7 @@ int tehmm_model_create(int N, int K, int S, const double *lt, const double *pi,
     R += cnt;
   }
   m->R = R;
-  std::vector<double> htab((size_t)R * NP, 0.0);
+  std::vector<double> htab((size_t)(R + 1) * NP, 0.0);     // row R: the zero padding (EmisTab::zero_row)
   for (int k = 0; k < K; ++k)
     for (int s = 0; s < m->rowcnt[k]; ++s)
       for (int j = 0; j < N; ++j)
@@ -368,11 +449,12 @@ int tehmm_model_create(int N, int K, int S, const double *lt, const double *pi,
     for (int k = 0; k < K; ++k) m->ldsbase[k] = -1;
     int used = 0;
     for (int k : ord) {
-      if ((size_t)(used + m->rowcnt[k]) > budget_rows) break;
+      if ((size_t)(used + m->rowcnt[k] + 1) > budget_rows) break;
       m->ldsbase[k] = used;
       used += m->rowcnt[k];
     }
-    m->lds_rows = used;
+    m->lds_zero = used;                  // one row of zeros behind the staged rows
+    m->lds_rows = used > 0 ? used + 1 : 0;
   }
   std::vector<double> hltab((size_t)std::max(1, m->lds_rows) * NP, 0.0);
   for (int k = 0; k < K; ++k)
@@ -552,6 +634,8 @@ static void fill_tabs(const tehmm_model *m, const tehmm_batch *b, IntervalTab &i
   std::memcpy(em.ldsbase, m->ldsbase, sizeof(em.ldsbase));
   em.lds_rows = m->lds_rows;
   em.ltab_src = m->ltab.p;
+  em.zero_row = m->R;
+  em.lds_zero = m->lds_zero;
 }
 
 // With more intervals than CUs the forward/backward kernel is throughput-bound: dropping the LDS
@@ -898,8 +982,10 @@ static void launch_vit_lane(tehmm_batch *b, const tehmm_model *m, const Interval
   const LaneGeom lg = lane_geom(lw);
   const VitItems vi = lane_vit_items(lw);
   if (n_work <= 0) return;
-  (void)lw.d_vc.upload(&vc, 1);
-  (void)lw.d_vi.upload(&vi, 1);
+  lw.hs_vc = vc;
+  lw.hs_vi = vi;
+  (void)lw.d_vc.fill_async(&lw.hs_vc, 1, st);
+  (void)lw.d_vi.fill_async(&lw.hs_vi, 1, st);
   const dim3 grid((n_work + 3) / 4);
   if (quant) {
     hipLaunchKernelGGL((k_vit_lane<NT, true>), grid, dim3(256), 0, st, iv, lg, (const VitChunks *)lw.d_vc.p,
@@ -1044,6 +1130,15 @@ static void launch_fb_fix(tehmm_batch *b, const tehmm_model *m, const IntervalTa
                      (double *)nullptr, (int *)nullptr, 1, b->sw.stats.p, LaneGeom(), (const int *)nullptr);
 }
 
+// -DTEHMM_DEV_NT=36: development builds that instantiate the fused kernels for one padded state
+// count only (seconds instead of minutes to compile); never used for the shipped library.
+#ifdef TEHMM_DEV_NT
+#define TEHMM_NT_DISPATCH(NP_, CALL)                                                                \
+  switch (NP_) {                                                                                    \
+    case TEHMM_DEV_NT: CALL(TEHMM_DEV_NT); break;                                                   \
+    default: break;                                                                                 \
+  }
+#else
 #define TEHMM_NT_DISPATCH(NP_, CALL)                                                                \
   switch (NP_) {                                                                                    \
     case 4: CALL(4); break;   case 8: CALL(8); break;   case 12: CALL(12); break;                   \
@@ -1053,6 +1148,7 @@ static void launch_fb_fix(tehmm_batch *b, const tehmm_model *m, const IntervalTa
     case 64: CALL(64); break;                                                                       \
     default: break;                                                                                 \
   }
+#endif
 
 int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *viterbi_logprob,
                      double *forward_logprob) {
@@ -1117,7 +1213,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   const char *wvs = std::getenv("TEHMM_LANE_WARMUP_VIT");
   const int WuV = std::min(LS, std::max(32, ((wvs ? std::atoi(wvs) : 32) + 31) & ~31));   // Viterbi warm-up (multiple of 32)
   VitChunks vc;
-  std::vector<double> gain;
+  std::vector<double> &gain = lw.hs_gain;
   if (vit) (void)hipEventRecord(b->ev[eV], b->sV);
   if (vlane || flane || glane) {
     rc = lane_prepare(b, m, CS, LS, flane, vlane, glane);
@@ -1279,23 +1375,26 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     if (vlane) {
       HIPCHK(hipStreamSynchronize(st));
       // item gains -> chunk gains -> binades; one P2 wave per (group, binade) pair
-      std::vector<double> cgain;
+      std::vector<double> &cgain = lw.hs_cgain;
       chunk_gains(cgain);
-      std::vector<int> he;
+      std::vector<int> &he = lw.hs_e;
       spec_assign_binades(b, cgain, he);
       // quantised tables of the binades in use
       int emin = INT_MAX, emax = INT_MIN;
       for (int c = 0; c < sw.n_chunks; ++c)
         if (he[(size_t)c] != TEHMM_SPEC_NONE) { emin = std::min(emin, he[(size_t)c]); emax = std::max(emax, he[(size_t)c]); }
-      std::vector<int> wk_g, wk_e;
+      std::vector<int> &wk_g = lw.hs_wkg, &wk_e = lw.hs_wke;
+      wk_g.clear();
+      wk_e.clear();
       if (emin <= emax) {
         const size_t tsz = (size_t)m->NP * m->NP;
-        std::vector<double> qt((size_t)(emax - emin + 1) * tsz);
+        std::vector<double> &qt = lw.hs_qt;
+        qt.resize((size_t)(emax - emin + 1) * tsz);
         std::vector<char> eok((size_t)(emax - emin + 1), 1);
         for (int e = emin; e <= emax; ++e) eok[(size_t)(e - emin)] = quantised_table(m, e, qt.data() + (size_t)(e - emin) * tsz);
         for (int c = 0; c < sw.n_chunks; ++c)
           if (he[(size_t)c] != TEHMM_SPEC_NONE && !eok[(size_t)(he[(size_t)c] - emin)]) he[(size_t)c] = TEHMM_SPEC_NONE;
-        HIPCHK(lw.qtabs.upload(qt.data(), qt.size()));
+        HIPCHK(lw.qtabs.fill_async(qt.data(), qt.size(), st));
         for (int g = 0; g < lw.n_groups; ++g) {
           int seen[8];
           int ns = 0;
@@ -1323,8 +1422,8 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       }
       const int n_work = (int)wk_g.size();
       if (n_work > 0) {
-        HIPCHK(lw.wk_g.upload(wk_g.data(), wk_g.size()));
-        HIPCHK(lw.wk_e.upload(wk_e.data(), wk_e.size()));
+        HIPCHK(lw.wk_g.fill_async(wk_g.data(), wk_g.size(), st));
+        HIPCHK(lw.wk_e.fill_async(wk_e.data(), wk_e.size(), st));
       }
       HIPCHK(hipMemcpyAsync(sw.e.p, he.data(), he.size() * sizeof(int), hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(sw.gain.p, cgain.data(), cgain.size() * sizeof(double), hipMemcpyHostToDevice, st));
@@ -1350,13 +1449,12 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
 #undef CALL
     } else if (vspec) {
       HIPCHK(hipStreamSynchronize(st));
-      std::vector<int> he;
+      std::vector<int> &he = lw.hs_e;
       if (glane) {
-        std::vector<double> cgain;
+        std::vector<double> &cgain = lw.hs_cgain;
         chunk_gains(cgain);
         spec_assign_binades(b, cgain, he);
         HIPCHK(hipMemcpyAsync(sw.gain.p, cgain.data(), cgain.size() * sizeof(double), hipMemcpyHostToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));          // cgain is a local
       } else {
         spec_assign_binades(b, gain, he);
       }
@@ -1489,8 +1587,19 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   }
   if ((flags & TEHMM_EVAL_VITERBI) && viterbi_logprob)
     HIPCHK(hipMemcpy(viterbi_logprob, b->vit_lp.p, (size_t)b->n * sizeof(double), hipMemcpyDeviceToHost));
-  if ((flags & TEHMM_EVAL_POSTERIOR) && forward_logprob)
-    HIPCHK(hipMemcpy(forward_logprob, b->fwd_lp.p, (size_t)b->n * sizeof(double), hipMemcpyDeviceToHost));
+  if (flags & TEHMM_EVAL_POSTERIOR) {
+    b->h_fwd_lp.resize((size_t)b->n);
+    HIPCHK(hipMemcpy(b->h_fwd_lp.data(), b->fwd_lp.p, (size_t)b->n * sizeof(double), hipMemcpyDeviceToHost));
+    if (forward_logprob) std::memcpy(forward_logprob, b->h_fwd_lp.data(), (size_t)b->n * sizeof(double));
+  }
+  return TEHMM_OK;
+}
+
+int tehmm_batch_get_interval_logprobs(tehmm_batch_t *b, double *out) {
+  if (!b || !out) return fail(TEHMM_ERR_ARG, "tehmm_batch_get_interval_logprobs: bad argument");
+  if (b->h_fwd_lp.size() != (size_t)b->n)
+    return fail(TEHMM_ERR_ARG, "tehmm_batch_get_interval_logprobs: no forward result in this batch");
+  if (b->n > 0) std::memcpy(out, b->h_fwd_lp.data(), (size_t)b->n * sizeof(double));
   return TEHMM_OK;
 }
 
@@ -1529,6 +1638,92 @@ int tehmm_batch_last_timing(tehmm_batch_t *b, int max_entries, const char **name
     if (ms) ms[i] = b->tms[i];
   }
   return n;
+}
+
+// ---- output reductions (bin/teHmmEval.py:238-275) ---------------------------------------------
+int tehmm_batch_posterior_masksum(tehmm_batch_t *b, const double *mask, int64_t row0, int64_t row1, double *out) {
+  if (!b || !mask || !out || row0 < 0 || row1 < row0 || row1 > b->total)
+    return fail(TEHMM_ERR_ARG, "tehmm_batch_posterior_masksum: bad argument");
+  if (!b->post.p) return fail(TEHMM_ERR_ARG, "tehmm_batch_posterior_masksum: no posterior result in this batch");
+  if (row1 == row0) return TEHMM_OK;
+  const int64_t rows = row1 - row0;
+  DBuf<double> d_mask, d_out;
+  HIPCHK(d_mask.upload(mask, (size_t)b->N));
+  HIPCHK(d_out.alloc((size_t)rows));
+  hipLaunchKernelGGL(k_post_masksum, dim3(grid_for(rows * 64, 256, 256 * 32)), dim3(256), 0, 0, rows, b->N,
+                     (const double *)(b->post.p + (size_t)row0 * b->N), (const double *)d_mask.p, d_out.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, d_out.p, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost));
+  return TEHMM_OK;
+}
+
+int tehmm_bed_coords(int64_t n_rows, int64_t table_start, int64_t table_end, const int64_t *segOffsets,
+                     const int32_t *maskOffsets, int64_t n_mask, int64_t *starts, int64_t *ends) {
+  if (n_rows < 0 || !starts || !ends || (maskOffsets && n_mask <= 0))
+    return fail(TEHMM_ERR_ARG, "tehmm_bed_coords: bad argument");
+  if (n_rows == 0) return TEHMM_OK;
+  if (maskOffsets) {
+    const int64_t dmax = segOffsets ? segOffsets[n_rows - 1] - segOffsets[0] : n_rows - 1;
+    if (dmax >= n_mask) return fail(TEHMM_ERR_ARG, "tehmm_bed_coords: maskOffsets shorter than the table");
+  }
+  DBuf<int64_t> d_seg, d_s, d_e;
+  DBuf<int32_t> d_m;
+  if (segOffsets) HIPCHK(d_seg.upload(segOffsets, (size_t)n_rows));
+  if (maskOffsets) HIPCHK(d_m.upload(maskOffsets, (size_t)n_mask));
+  HIPCHK(d_s.alloc((size_t)n_rows));
+  HIPCHK(d_e.alloc((size_t)n_rows));
+  hipLaunchKernelGGL(k_bed_coords, dim3(grid_for(n_rows, 256)), dim3(256), 0, 0, n_rows, table_start, table_end,
+                     (const int64_t *)d_seg.p, (const int32_t *)d_m.p, d_s.p, d_e.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(starts, d_s.p, (size_t)n_rows * sizeof(int64_t), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(ends, d_e.p, (size_t)n_rows * sizeof(int64_t), hipMemcpyDeviceToHost));
+  return TEHMM_OK;
+}
+
+// Host-side text writer of the per-row BED lines ("%s\t%d\t%d\t%s\n", teHmmEval.py:266-275): the
+// reference formats every line in the interpreter, which dominates its wall-clock at 100 Mb.
+// 4th column: names[states[i]] (or the integer state when names is NULL) -- or, when values is not NULL,
+// values[i] printed the way Python 2 prints a numpy float64 ("%.12g", plus ".0" for integral values).
+int tehmm_write_bed(const char *path, int append, const char *chrom, int64_t n, const int64_t *starts,
+                    const int64_t *ends, const int64_t *states, int n_names, const char *const *names,
+                    const double *values) {
+  if (!path || !chrom || n < 0 || !starts || !ends || (!states && !values))
+    return fail(TEHMM_ERR_ARG, "tehmm_write_bed: bad argument");
+  FILE *f = std::fopen(path, append ? "a" : "w");
+  if (!f) return fail(TEHMM_ERR_ARG, std::string("tehmm_write_bed: cannot open ") + path);
+  std::string buf;
+  buf.reserve(1 << 22);
+  char num[64];
+  const size_t clen = std::strlen(chrom);
+  int rc = TEHMM_OK;
+  for (int64_t i = 0; i < n && rc == TEHMM_OK; ++i) {
+    buf.append(chrom, clen);
+    int k = std::snprintf(num, sizeof(num), "\t%lld\t%lld\t", (long long)starts[i], (long long)ends[i]);
+    buf.append(num, (size_t)k);
+    if (values) {
+      k = std::snprintf(num, sizeof(num), "%.12g", values[i]);
+      bool plain = true;
+      for (int q = 0; q < k; ++q) plain = plain && ((num[q] >= '0' && num[q] <= '9') || num[q] == '-');
+      buf.append(num, (size_t)k);
+      if (plain) buf.append(".0");
+    } else if (names) {
+      const int64_t st = states[i];
+      if (st < 0 || st >= n_names || !names[st]) rc = fail(TEHMM_ERR_ARG, "tehmm_write_bed: state without a name");
+      else buf.append(names[st]);
+    } else {
+      k = std::snprintf(num, sizeof(num), "%lld", (long long)states[i]);
+      buf.append(num, (size_t)k);
+    }
+    buf.push_back('\n');
+    if (buf.size() > (1u << 22) - 256) {
+      if (std::fwrite(buf.data(), 1, buf.size(), f) != buf.size()) rc = fail(TEHMM_ERR_ARG, "tehmm_write_bed: write failed");
+      buf.clear();
+    }
+  }
+  if (rc == TEHMM_OK && !buf.empty() && std::fwrite(buf.data(), 1, buf.size(), f) != buf.size())
+    rc = fail(TEHMM_ERR_ARG, "tehmm_write_bed: write failed");
+  if (std::fclose(f) != 0 && rc == TEHMM_OK) rc = fail(TEHMM_ERR_ARG, "tehmm_write_bed: close failed");
+  return rc;
 }
 
 // Array-level Viterbi: one interval, frame input, through the same kernel + traceback.
@@ -1629,7 +1824,7 @@ void launch_estep(const tehmm_model *m, const IntervalTab &iv, const EmisTab &em
     allow_lds(k_estep_accum<NT, true>, lds2);
     hipLaunchKernelGGL((k_estep_accum<NT, true>), dim3((n_chunks + 3) / 4), dim3(256), lds2, st, iv, em,
                        m->N, kEstepChunk, w.chunk_iv.p, w.chunk_t0.p, n_chunks, w.alpha.p, w.beta.p,
-                       w.wrows.p, w.escale.p, w.C.p, w.D.p, w.start.p, w.stat.p);
+                       w.wrows.p, w.escale.p, w.C, w.D, w.start, w.stat);
   } else {
     allow_lds(k_fb_coop<NT, CPB, false>, lds);
     hipLaunchKernelGGL((k_fb_coop<NT, CPB, false>), dim3(n_iv), dim3(256), lds, st, iv, emf, m->N, m->A.p,
@@ -1638,21 +1833,22 @@ void launch_estep(const tehmm_model *m, const IntervalTab &iv, const EmisTab &em
     allow_lds(k_estep_accum<NT, false>, lds2);
     hipLaunchKernelGGL((k_estep_accum<NT, false>), dim3((n_chunks + 3) / 4), dim3(256), lds2, st, iv, em,
                        m->N, kEstepChunk, w.chunk_iv.p, w.chunk_t0.p, n_chunks, w.alpha.p, w.beta.p,
-                       w.wrows.p, w.escale.p, w.C.p, w.D.p, w.start.p, w.stat.p);
+                       w.wrows.p, w.escale.p, w.C, w.D, w.start, w.stat);
   }
 }
 }  // namespace
 
-int tehmm_estep_batch(tehmm_model_t *m, tehmm_batch_t *b, int use_ratios, double *start,
-                      double *trans, double *obsStats, double *logprob_sum) {
-  if (!m || !b || !start || !trans || !obsStats || !logprob_sum)
-    return fail(TEHMM_ERR_ARG, "tehmm_estep_batch: NULL argument");
-  if (m->K != b->K) return fail(TEHMM_ERR_ARG, "tehmm_estep_batch: model/batch track count differ");
-  if (m->N >= 64) return fail(TEHMM_ERR_UNSUPPORTED, "tehmm_estep_batch: N >= 64 (use the array-level path)");
-  *logprob_sum = 0.0;
+// Raw statistics of every interval of the batch ADDED into dev_stats (device buffer of
+// stats_size(NP, R) doubles, layout in tehmm_aux.hip.h); *dead_any: some interval met an impossible row
+// after its first emittable one (the reference's lattices are NaN there).
+static int estep_accumulate(tehmm_model_t *m, tehmm_batch_t *b, int use_ratios, double *dev_stats, double *lp_out,
+                            int *dead_out) {
+  *lp_out = 0.0;
+  *dead_out = 0;
+  b->h_fwd_lp.assign((size_t)b->n, 0.0);
   if (b->n == 0 || b->total == 0) return TEHMM_OK;
   const bool ratio = use_ratios && b->has_ratios;
-  const int N = m->N, NP = m->NP, K = m->K, S = m->S;
+  const int N = m->N, NP = m->NP;
   // Intervals are processed in groups whose alpha / beta / w rows fit a fixed workspace
   // (3 x 8N + 4 bytes per position, 40 % of the free HBM): the 3 Gb training sets of config 4
   // never materialise whole-genome lattices.
@@ -1662,19 +1858,15 @@ int tehmm_estep_batch(tehmm_model_t *m, tehmm_batch_t *b, int use_ratios, double
   if (budget_bytes < (4ll << 30)) budget_bytes = 4ll << 30;
   const int64_t budget_rows = std::max<int64_t>(budget_bytes / (24 * N + 4), 1);
   EstepWork &w = b->ew;
-  if (w.N != N || !w.C.p) {
-    HIPCHK(w.C.alloc((size_t)NP * NP));
-    HIPCHK(w.D.alloc((size_t)NP));
-    HIPCHK(w.start.alloc((size_t)NP));
-    HIPCHK(w.stat.alloc((size_t)m->R * NP));
+  if (w.N != N) {
     w.alpha.release();
     w.rows_cap = 0;
     w.N = N;
   }
-  HIPCHK(hipMemset(w.C.p, 0, (size_t)NP * NP * sizeof(double)));
-  HIPCHK(hipMemset(w.D.p, 0, (size_t)NP * sizeof(double)));
-  HIPCHK(hipMemset(w.start.p, 0, (size_t)NP * sizeof(double)));
-  HIPCHK(hipMemset(w.stat.p, 0, (size_t)m->R * NP * sizeof(double)));
+  w.start = dev_stats + stats_off_start();
+  w.C = dev_stats + stats_off_C(NP);
+  w.D = dev_stats + stats_off_D(NP);
+  w.stat = dev_stats + stats_off_stat(NP);
   IntervalTab iv;
   EmisTab em;
   fill_tabs(m, b, iv, em, ratio);     // fit applies the ratios to emissions too (basehmm.py:510)
@@ -1736,13 +1928,64 @@ int tehmm_estep_batch(tehmm_model_t *m, tehmm_batch_t *b, int use_ratios, double
     for (int id : g_order) {
       lp_total += lp[(size_t)id];
       dead_any |= dead[(size_t)id];
+      b->h_fwd_lp[(size_t)id] = dead[(size_t)id] ? std::nan("") : lp[(size_t)id];
     }
   }
-  std::vector<double> hC((size_t)NP * NP), hD(NP), hS(NP), hst((size_t)m->R * NP);
-  HIPCHK(hipMemcpy(hC.data(), w.C.p, hC.size() * sizeof(double), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(hD.data(), w.D.p, hD.size() * sizeof(double), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(hS.data(), w.start.p, hS.size() * sizeof(double), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(hst.data(), w.stat.p, hst.size() * sizeof(double), hipMemcpyDeviceToHost));
+  *lp_out = lp_total;
+  *dead_out = dead_any;
+  return TEHMM_OK;
+}
+
+int64_t tehmm_model_stats_size(const tehmm_model_t *m) { return m ? stats_size(m->NP, m->R) : 0; }
+
+int tehmm_estep_batch_device(tehmm_model_t *m, tehmm_batch_t *b, int use_ratios, double *dev_stats,
+                             double *logprob_sum) {
+  if (!m || !b || !dev_stats || !logprob_sum)
+    return fail(TEHMM_ERR_ARG, "tehmm_estep_batch_device: NULL argument");
+  if (m->K != b->K) return fail(TEHMM_ERR_ARG, "tehmm_estep_batch_device: model/batch track count differ");
+  if (m->N >= 64) return fail(TEHMM_ERR_UNSUPPORTED, "tehmm_estep_batch_device: N >= 64 (use the array-level path)");
+  double lp = 0.0;
+  int dead = 0;
+  int rc = estep_accumulate(m, b, use_ratios, dev_stats, &lp, &dead);
+  if (rc) return rc;
+  const double nan = std::nan("");
+  // slots 0 / 1 of the buffer: log-likelihood sum (NaN poisons it, as the reference's NaN lattices would)
+  // and sequence count -- they travel with the statistics through the all-reduce
+  double head[2];
+  HIPCHK(hipMemcpy(head, dev_stats, sizeof(head), hipMemcpyDeviceToHost));
+  head[0] += dead ? nan : lp;
+  head[1] += (double)b->n;
+  HIPCHK(hipMemcpy(dev_stats, head, sizeof(head), hipMemcpyHostToDevice));
+  if (dead) {      // the reference's statistics are NaN from such a sequence on: poison the buffer
+    std::vector<double> bad((size_t)stats_size(m->NP, m->R), nan);
+    bad[1] = head[1];
+    HIPCHK(hipMemcpy(dev_stats, bad.data(), bad.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  *logprob_sum = dead ? nan : lp;
+  return TEHMM_OK;
+}
+
+int tehmm_estep_batch(tehmm_model_t *m, tehmm_batch_t *b, int use_ratios, double *start,
+                      double *trans, double *obsStats, double *logprob_sum) {
+  if (!m || !b || !start || !trans || !obsStats || !logprob_sum)
+    return fail(TEHMM_ERR_ARG, "tehmm_estep_batch: NULL argument");
+  if (m->K != b->K) return fail(TEHMM_ERR_ARG, "tehmm_estep_batch: model/batch track count differ");
+  if (m->N >= 64) return fail(TEHMM_ERR_UNSUPPORTED, "tehmm_estep_batch: N >= 64 (use the array-level path)");
+  *logprob_sum = 0.0;
+  if (b->n == 0 || b->total == 0) return TEHMM_OK;
+  const int N = m->N, NP = m->NP, K = m->K, S = m->S;
+  EstepWork &w = b->ew;
+  const size_t ssz = (size_t)stats_size(NP, m->R);
+  HIPCHK(w.statbuf.ensure(ssz));
+  HIPCHK(hipMemset(w.statbuf.p, 0, ssz * sizeof(double)));
+  double lp_total = 0.0;
+  int dead_any = 0;
+  int rc = estep_accumulate(m, b, use_ratios, w.statbuf.p, &lp_total, &dead_any);
+  if (rc) return rc;
+  std::vector<double> hs(ssz);
+  HIPCHK(hipMemcpy(hs.data(), w.statbuf.p, ssz * sizeof(double), hipMemcpyDeviceToHost));
+  const double *hS = hs.data() + stats_off_start(), *hC = hs.data() + stats_off_C(NP),
+               *hD = hs.data() + stats_off_D(NP), *hst = hs.data() + stats_off_stat(NP);
   const double nan = std::nan("");
   const double invN = 1.0 / (double)N;
   for (int i = 0; i < N; ++i) {
@@ -1760,6 +2003,8 @@ int tehmm_estep_batch(tehmm_model_t *m, tehmm_batch_t *b, int use_ratios, double
   *logprob_sum = dead_any ? nan : lp_total;
   return TEHMM_OK;
 }
+
+#include "tehmm_aux_host.inc"
 
 // Diagnostic: cycle stamps of the last cooperative kernel (only in the -DTEHMM_STAMPS build).
 int tehmm_debug_read_stamps(unsigned long long *out, int n) {

@@ -65,6 +65,10 @@ struct EmisTab {
   int ldsbase[TEHMM_MAX_TRACKS];
   int lds_rows;
   const double *ltab_src;  // [lds_rows][NP] the LDS-resident rows, packed
+  // A symbol beyond a track's last one reads the reference's zero padding (logProbs is
+  // [K][N][1 + max symbols], emission.py:136-138): row zero_row of tab / row lds_zero of the LDS
+  // copy hold zeros for it (lds_zero is only meaningful while lds_rows > 0).
+  int zero_row, lds_zero;
 };
 
 struct IntervalTab {
@@ -107,8 +111,8 @@ __device__ __forceinline__ void emis_log(const EmisTab &e, int64_t gpos, int lan
   for (int k = 0; k < e.K; ++k) {
     uint32_t w = row[k >> 2];
     int sym = (int)((w >> ((k & 3) * 8)) & 0xffu);
-    sym = min(sym, e.rowcnt[k] - 1);
-    const double *tr = e.tab + (int64_t)(e.rowbase[k] + sym) * e.NP;
+    const int trow = sym < e.rowcnt[k] ? e.rowbase[k] + sym : e.zero_row;
+    const double *tr = e.tab + (int64_t)trow * e.NP;
 #pragma unroll
     for (int s = 0; s < SPL; ++s) {
       int j = lane + TEHMM_WAVE * s;
@@ -173,7 +177,8 @@ __global__ void k_emission(int64_t T, int K, int N, int S, const ObsT *obs, cons
     double x = 0.0;
     for (int k = 0; k < K; ++k) {
       int64_t sym = (int64_t)obs[t * K + k];
-      x += lp[((int64_t)k * N + j) * S + sym];
+      // (the reference indexes unchecked, quirk Q10; a symbol outside the table contributes nothing here)
+      if (sym >= 0 && sym < S) x += lp[((int64_t)k * N + j) * S + sym];
     }
     x *= normalize;
     if (ratios) x *= ratios[t];
@@ -323,10 +328,11 @@ __global__ void k_xi_logsum(int64_t T, int N, const double *fwd, const double *l
 }
 
 // ------------------------------------------------------------------------------------------
-// Array-level emission statistics (_emission.pyx:165-190): one thread per (track, state) row of
+// Array-level emission statistics (_emission.pyx:165-234): one thread per (track, state) row of
 // obsStats, sequential over t (same accumulation order as the reference, no atomics).
 // ------------------------------------------------------------------------------------------
-__global__ void k_accumulate_obs(int64_t T, int K, int N, int S, const uint8_t *obs,
+template <typename ObsT>
+__global__ void k_accumulate_obs(int64_t T, int K, int N, int S, const ObsT *obs,
                                  double *obsStats, const double *post, const double *ratios) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= K * N) return;
@@ -335,7 +341,78 @@ __global__ void k_accumulate_obs(int64_t T, int K, int N, int S, const uint8_t *
   for (int64_t t = 0; t < T; ++t) {
     double p = post[t * N + j];
     if (ratios) p *= ratios[t];
-    row[obs[t * K + k]] += p;
+    const int64_t sym = (int64_t)obs[t * K + k];
+    if (sym >= 0 && sym < S) row[sym] += p;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Supervised emission counts (fastUpdateCounts -> _fastUpdateCountsU8/U16/32, _emission.pyx:236-332):
+//   for pos in [start, end): obsStats[track][state][obs[pos][track]] += (ratios ? ratios[pos] : 1.0)
+// for MANY labelled intervals at once (the reference calls it once per BED interval,
+// emission.py:307-322).  Every cell of obsStats is owned by one thread, which walks the intervals in
+// the given order and their positions ascending -- the reference's accumulation order, so the
+// segment-ratio sums round identically.  grid = (K, N), threads = symbol values (strided).
+//   iv_start / iv_end / iv_state: [n_iv] table-relative ranges and integer state labels
+// ------------------------------------------------------------------------------------------
+template <typename ObsT>
+__global__ void k_update_counts(int n_iv, const int64_t *iv_start, const int64_t *iv_end,
+                                const int32_t *iv_state, int K, int N, int S, const ObsT *obs,
+                                double *obsStats, const double *ratios) {
+  const int k = blockIdx.x, state = blockIdx.y;
+  for (int sym = threadIdx.x; sym < S; sym += blockDim.x) {
+    double acc = obsStats[((int64_t)k * N + state) * S + sym];
+    bool touched = false;
+    for (int i = 0; i < n_iv; ++i) {
+      if (iv_state[i] != state) continue;
+      for (int64_t pos = iv_start[i]; pos < iv_end[i]; ++pos) {
+        if ((int64_t)obs[pos * K + k] == (int64_t)sym) {
+          acc += ratios ? ratios[pos] : 1.0;
+          touched = true;
+        }
+      }
+    }
+    if (touched) obsStats[((int64_t)k * N + state) * S + sym] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Output reductions of teHmmEval (bin/teHmmEval.py:238-275).
+//   k_post_masksum: out[r] = sum_j post[r][j] * mask[j]   (the --pd / --pdStates column, :270-272);
+//                   one wave per row, lane = state.
+//   k_bed_coords  : BED coordinates of every row of a (possibly segmented, possibly masked) table
+//                   (:243-266): start = tableStart + d_i + maskOff[d_i], end = start + len_i with
+//                   d_i = segOffsets[i] - segOffsets[0] (i for unsegmented tables) and
+//                   len_i = TrackTable.getSegmentLength(i) (track.py:497-502).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_post_masksum(int64_t rows, int N, const double *post,
+                                                      const double *mask, double *out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  double mk[2] = {lane < N ? mask[lane] : 0.0, lane + 64 < N ? mask[lane + 64] : 0.0};
+  for (int64_t r = wid; r < rows; r += nw) {
+    double g = lane < N ? post[r * N + lane] * mk[0] : 0.0;
+    if (lane + 64 < N) g += post[r * N + lane + 64] * mk[1];
+    g = wave_sum_f64(g);
+    if (lane == 0) out[r] = g;
+  }
+}
+
+__global__ void k_bed_coords(int64_t n_rows, int64_t table_start, int64_t table_end,
+                             const int64_t *segOffsets, const int32_t *maskOffsets, int64_t *starts,
+                             int64_t *ends) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_rows;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t d = i, len = 1;
+    if (segOffsets) {
+      d = segOffsets[i] - segOffsets[0];
+      len = i + 1 < n_rows ? segOffsets[i + 1] - segOffsets[i] : table_end - (table_start + segOffsets[i]);
+    }
+    int64_t st = table_start + d;
+    if (maskOffsets) st += maskOffsets[d];
+    starts[i] = st;
+    ends[i] = st + len;
   }
 }
 

@@ -71,34 +71,79 @@ def allreduce_stats(stats, logprob):
     return unpack_stats(t.cpu().numpy(), stats)
 
 
-def gather_interval_scalars(local_idx, local_values, n_total):
-    """All ranks get the full per-interval array (e.g. Viterbi log-probs) of a sharded batch."""
+def allreduce_device_stats(stats):
+    """The one collective of an EM iteration, in place on the device buffer of the raw statistics
+    (engine.DeviceStats).  nccl backend: RCCL all-reduce of the buffer's torch tensor over xGMI;
+    any other backend (gloo in the CPU tests) cannot see device memory and is refused."""
+    dist = _dist()
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    if stats.tensor is None:
+        raise RuntimeError("device-resident statistics need the nccl backend for the all-reduce")
+    dist.all_reduce(stats.tensor, op=dist.ReduceOp.SUM)
+
+
+def gather_interval_scalars(local_idx, local_values, n_total, lengths=None):
+    """All ranks get the full per-interval array (e.g. Viterbi log-probs) of a sharded batch: one
+    all-gather of (index, value) pairs padded to the largest shard."""
     import torch
     dist = _dist()
     full = np.zeros(n_total, dtype=np.float64)
-    full[np.asarray(local_idx, dtype=np.int64)] = np.asarray(local_values, dtype=np.float64)
+    local_idx = np.asarray(local_idx, dtype=np.int64)
+    full[local_idx] = np.asarray(local_values, dtype=np.float64)
     if dist.is_initialized() and dist.get_world_size() > 1:
-        t = torch.from_numpy(full).to(_device_for_backend())
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)          # disjoint supports: a sum is a gather
-        full = t.cpu().numpy()
+        world = dist.get_world_size()
+        cap = (n_total + world - 1) // world + 1
+        cnt = torch.tensor([len(local_idx)], dtype=torch.int64, device=_device_for_backend())
+        cmax = cnt.clone()
+        dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+        cap = max(cap, int(cmax.item()))
+        buf = np.full((cap, 2), -1.0, dtype=np.float64)
+        buf[:len(local_idx), 0] = local_idx
+        buf[:len(local_idx), 1] = np.asarray(local_values, dtype=np.float64)
+        send = torch.from_numpy(buf).to(_device_for_backend())
+        recv = torch.empty((world * cap, 2), dtype=torch.float64, device=send.device)
+        dist.all_gather_into_tensor(recv, send)
+        recv = recv.cpu().numpy()
+        ok = recv[:, 0] >= 0
+        full[recv[ok, 0].astype(np.int64)] = recv[ok, 1]
     return full
 
 
 def gather_paths(local_idx, local_paths, lengths):
-    """Trivial gather of the variable-length per-interval Viterbi paths to every rank:
-    paths are concatenated in global interval order."""
+    """Gather of the variable-length per-interval Viterbi paths to every rank: ONE all-gather of the
+    ranks' concatenated paths as uint8 (states < 256: 1 byte per position on the wire instead of the
+    reference's int64), padded to the largest shard; returned in global interval order as int64."""
     import torch
     dist = _dist()
     lengths = np.asarray(lengths, dtype=np.int64)
-    offs = np.concatenate([[0], np.cumsum(lengths)])
-    full = np.zeros(int(offs[-1]), dtype=np.int64)
-    for i, p in zip(local_idx, local_paths):
-        full[offs[i]:offs[i + 1]] = p
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        t = torch.from_numpy(full).to(_device_for_backend())
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        full = t.cpu().numpy()
-    return [full[offs[i]:offs[i + 1]] for i in range(len(lengths))]
+    n = len(lengths)
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        out = [None] * n
+        for i, p in zip(local_idx, local_paths):
+            out[int(i)] = np.asarray(p, dtype=np.int64)
+        return out
+    world = dist.get_world_size()
+    shards = lpt_shard(lengths, world)
+    sizes = [int(lengths[s].sum()) for s in shards]
+    cap = max(max(sizes), 1)
+    dev = _device_for_backend()
+    mine = np.zeros(cap, dtype=np.uint8)
+    if len(local_paths):
+        cat = np.concatenate([np.asarray(p) for p in local_paths]) if len(local_paths) > 1 else np.asarray(local_paths[0])
+        assert cat.size == 0 or int(cat.max()) < 256
+        mine[:cat.size] = cat.astype(np.uint8)
+    send = torch.from_numpy(mine).to(dev)
+    recv = torch.empty(world * cap, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(recv, send)
+    recv = recv.cpu().numpy().reshape(world, cap)
+    out = [None] * n
+    for r, shard in enumerate(shards):
+        o = 0
+        for i in shard:
+            out[int(i)] = recv[r, o:o + int(lengths[i])].astype(np.int64)
+            o += int(lengths[i])
+    return out
 
 
 class ShardedEvaluator(object):

@@ -13,7 +13,7 @@ import numpy as np
 from numpy.testing import assert_array_almost_equal
 from scipy import stats
 
-from ._emission import canFast, fastAccumulateStats, fastAllLogProbs
+from ._emission import canFast, fastAccumulateStats, fastAllLogProbs, fastUpdateCountsBatch
 from .common import EPSILON, logger, myLog, normalize
 from .track import TrackTable
 
@@ -158,6 +158,35 @@ class IndependentMultinomialEmissionModel(object):
                     self.logProbs[track][state][symbol] = myLog(symbolProb, logZeroVal=-1e6)
                 if trackSum < EPSILON:
                     self.logProbs[track][state] = lastMat
+        self.validate()
+
+    def supervisedTrain(self, trackData, bedIntervals):
+        """emission.py:293-330: emission counts of every state from sorted labelled intervals.  The
+        reference updates the counts one overlap at a time (fastUpdateCounts); here the overlaps are
+        gathered per table, in the same order, and every table is ONE device call."""
+        tables = trackData.getTrackTableList()
+        assert len(tables) > 0 and len(bedIntervals) > 0
+        obsStats = self.initStats()
+        per_table = [[] for _ in tables]
+        lastHit, lastOverlapEnd = 0, -1
+        for interval in bedIntervals:
+            hit = False
+            for tableIdx in range(lastHit, len(tables)):
+                overlap = tables[tableIdx].getOverlapInTableCoords(interval, lastOverlapEnd)
+                if overlap is not None:
+                    lastHit, hit = tableIdx, True
+                    lastOverlapEnd = max(0, overlap[2] - 1)
+                    per_table[tableIdx].append(overlap)
+                elif hit is True:
+                    break
+        for table, overlaps in zip(tables, per_table):
+            if not overlaps:
+                continue
+            if canFast(table):
+                fastUpdateCountsBatch(overlaps, table, obsStats, self.getSegmentRatios(table))
+            else:
+                raise TypeError("supervisedTrain needs integer TrackTables")
+        self.maximize(obsStats, trackData.getTrackList())
         self.validate()
 
     def validate(self):

@@ -52,6 +52,40 @@ class HipModel(object):
         batch.N = self.N
         return {"viterbi_logprob": vlp, "forward_logprob": flp}
 
+    def estep_device(self, batch, use_ratios, stats):
+        """E-step with the raw statistics ADDED into the device buffer `stats` (DeviceStats)."""
+        lp = ctypes.c_double(0.0)
+        _lib.check(_lib.load().tehmm_estep_batch_device(self._h, batch._h, int(bool(use_ratios)), stats.ptr,
+                                                        ctypes.byref(lp)), "tehmm_estep_batch_device")
+        return lp.value
+
+    def mstep(self, stats, do_start, do_trans, do_emission, start_prior, trans_prior, fudge, gauss=None):
+        """MultitrackHmm._do_mstep on the device; gauss = (track indices, values [n][S], uniform mix) or
+        None.  Returns the gaussian (mu, sigma) table [n][N][2] or None."""
+        n_g, gt, gv, mix, gp = 0, None, None, 0.1, None
+        if gauss is not None:
+            gt = np.ascontiguousarray(gauss[0], dtype=np.int32)
+            gv = np.ascontiguousarray(gauss[1], dtype=np.float64)
+            mix = float(gauss[2])
+            n_g = len(gt)
+            assert gv.shape == (n_g, self.S)
+            gp = np.zeros((n_g, self.N, 2), dtype=np.float64)
+        _lib.check(_lib.load().tehmm_model_mstep(self._h, stats.ptr, int(bool(do_start)), int(bool(do_trans)),
+                                                 int(bool(do_emission)), float(start_prior), float(trans_prior),
+                                                 float(fudge), n_g, ptr(gt, i32p), ptr(gv, f64p), mix,
+                                                 ptr(gp, f64p)), "tehmm_model_mstep")
+        return gp
+
+    def get_params(self, log_probs_like):
+        """(log_transmat [N,N], log_startprob [N], logProbs [K,N,S]) of the handle; the padding cells of
+        logProbs are taken from `log_probs_like`."""
+        lt = np.zeros((self.N, self.N), dtype=np.float64)
+        pi = np.zeros(self.N, dtype=np.float64)
+        lp = np.ascontiguousarray(log_probs_like, dtype=np.float64).copy()
+        _lib.check(_lib.load().tehmm_model_get_params(self._h, ptr(lt, f64p), ptr(pi, f64p), ptr(lp, f64p)),
+                   "tehmm_model_get_params")
+        return lt, pi, lp
+
     def estep(self, batch, use_ratios, start, trans, obs_stats):
         """Accumulate Baum-Welch sufficient statistics of every interval into the given arrays;
         returns the summed forward log-likelihood."""
@@ -63,6 +97,55 @@ class HipModel(object):
                                                  ptr(obs_stats, f64p), ctypes.byref(lp)),
                    "tehmm_estep_batch")
         return lp.value
+
+
+class DeviceStats(object):
+    """The flat fp64 buffer of raw E-step statistics on the device (include/tehmm_hip.h,
+    "device-resident Baum-Welch").  With torch.distributed initialised on the nccl backend the buffer
+    is a torch CUDA tensor, so that RCCL all-reduces it in place; otherwise the library allocates it."""
+
+    def __init__(self, model):
+        self.model = model
+        self.size = int(_lib.load().tehmm_model_stats_size(model._h))
+        self.tensor = None
+        self._own = None
+        t = _dist_tensor(self.size)
+        if t is not None:
+            self.tensor = t
+            self.ptr = ctypes.c_void_p(t.data_ptr())
+        else:
+            p = vp()
+            _lib.check(_lib.load().tehmm_stats_alloc(model._h, ctypes.byref(p)), "tehmm_stats_alloc")
+            self._own = p
+            self.ptr = p
+
+    def zero(self):
+        _lib.check(_lib.load().tehmm_stats_zero(self.model._h, self.ptr), "tehmm_stats_zero")
+
+    def head(self):
+        lp, n = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        _lib.check(_lib.load().tehmm_stats_head(self.ptr, ctypes.byref(lp), ctypes.byref(n)), "tehmm_stats_head")
+        return lp.value, n.value
+
+    def close(self):
+        if self._own is not None:
+            _lib.load().tehmm_stats_free(self._own)
+            self._own = None
+        self.tensor = None
+
+    __del__ = close
+
+
+def _dist_tensor(size):
+    """A zeroed CUDA tensor when this process is a rank of an nccl (= RCCL) process group, else None."""
+    try:
+        import torch
+        import torch.distributed as dist
+    except ImportError:
+        return None
+    if not (dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"):
+        return None
+    return torch.zeros(size, dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
 
 
 class HipBatch(object):
@@ -115,6 +198,25 @@ class HipBatch(object):
         out = np.empty((row1 - row0, n_states), dtype=np.float64)
         _lib.check(_lib.load().tehmm_batch_get_posteriors(self._h, row0, row1, ptr(out, f64p)),
                    "tehmm_batch_get_posteriors")
+        return out
+
+    def interval_logprobs(self):
+        """Per-interval forward log-likelihoods of the last estep / posterior evaluation."""
+        out = np.zeros(self.n, dtype=np.float64)
+        _lib.check(_lib.load().tehmm_batch_get_interval_logprobs(self._h, ptr(out, f64p)),
+                   "tehmm_batch_get_interval_logprobs")
+        return out
+
+    def posterior_masksum(self, mask, row0=0, row1=None):
+        """sum_j posteriors[r, j] * mask[j] for rows [row0, row1) (teHmmEval.py:270-272), reduced on
+        the device: 8 instead of 8 N bytes per row cross PCIe."""
+        row1 = self.total if row1 is None else row1
+        mask = np.ascontiguousarray(mask, dtype=np.float64)
+        assert mask.shape[0] == self.N
+        out = np.empty(row1 - row0, dtype=np.float64)
+        _lib.check(_lib.load().tehmm_batch_posterior_masksum(self._h, ptr(mask, f64p), row0, row1,
+                                                             ptr(out, f64p)),
+                   "tehmm_batch_posterior_masksum")
         return out
 
     def device_ptrs(self):

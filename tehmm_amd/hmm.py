@@ -79,6 +79,35 @@ class MultitrackHmm(BaseHMM):
             self.last_forward_log_prob_it = self.bestCopy.last_forward_log_prob_it
         self.validate()
 
+    def supervisedTrain(self, trackData, bedIntervals):
+        """hmm.py:174-210: transition / start counts from sorted labelled intervals
+        (chrom, start, end, state), emissions through emissionModel.supervisedTrain."""
+        self.trackList = trackData.getTrackList()
+        N = self.emissionModel.getNumStates()
+        transitionCount = self.fudge + np.zeros((N, N), dtype=np.float64)
+        freqCount = self.fudge + np.zeros((N,), dtype=np.float64)
+        prevInterval = None
+        for interval in bedIntervals:
+            state = int(interval[3])
+            assert state < N
+            transitionCount[state, state] += interval[2] - interval[1] - 1
+            freqCount[state] += interval[2] - interval[1]
+            if prevInterval is not None and prevInterval[0] == interval[0]:
+                if interval[1] < prevInterval[2]:
+                    raise RuntimeError("Overlapping or out of order training intervals detected: "
+                                       "%s and %s." % (prevInterval, interval))
+                elif interval[1] == prevInterval[2]:
+                    transitionCount[prevInterval[3], state] += 1
+            prevInterval = interval
+        for row in range(len(transitionCount)):
+            transitionCount[row] /= np.sum(transitionCount[row])
+        self.transmat_ = np.copy(transitionCount)
+        self._log_transmat = np.asarray(myLog(transitionCount), dtype=np.float64)
+        freqCount /= np.sum(freqCount)
+        self.startprob_ = freqCount
+        self.emissionModel.supervisedTrain(trackData, bedIntervals)
+        self.validate()
+
     def viterbi(self, trackData, numThreads=1):
         """(logprob, states) per table (hmm.py:221-237) -- all tables in one fused launch."""
         assert numThreads == 1
@@ -158,6 +187,9 @@ class MultitrackHmm(BaseHMM):
         """decode and/or score_samples over a list of tables.  Ratio semantics exactly as the
         reference drivers: emission never sees ratios; Viterbi transitions do (Q11); posteriors
         never (Q12)."""
+        if len(tables) == 0:
+            return {"viterbi_logprob": np.zeros(0), "paths": [], "forward_logprob": np.zeros(0),
+                    "posteriors": []}
         if not self._can_fuse(tables):
             out = {"viterbi_logprob": [], "paths": [], "forward_logprob": [], "posteriors": []}
             for t in tables:
@@ -287,6 +319,7 @@ class MultitrackHmm(BaseHMM):
         trans = np.zeros((N, N))
         obs_stats = np.zeros_like(stats['obs'])
         total_lp = 0.0
+        seq_lp = np.zeros(len(tables))
         for has_r, idx in groups.items():
             if not idx:
                 continue
@@ -296,6 +329,7 @@ class MultitrackHmm(BaseHMM):
             rcat = np.concatenate([ratios[i] for i in idx]) if has_r else None
             hb = HipBatch(obs, offs, rcat)
             total_lp += hm.estep(hb, has_r, start, trans, obs_stats)
+            seq_lp[idx] = hb.interval_logprobs()
             hb.close()
         stats['nobs'] += len(tables)
         if 's' in self.params:
@@ -304,7 +338,8 @@ class MultitrackHmm(BaseHMM):
             stats['trans'] += trans
         if 'e' in self.params:
             stats['obs'] += obs_stats
-        self._note_forward_logprob(total_lp, whole_iteration=True)
+        for lp in seq_lp:                    # the reference books every sequence's forward pass in turn
+            self._note_forward_logprob(float(lp))
         return total_lp
 
     def _do_mstep(self, stats, params):
@@ -333,7 +368,108 @@ class MultitrackHmm(BaseHMM):
 
     def fit(self, obs, **kwargs):
         self.current_iteration = 1
+        if self._can_fit_on_device(obs):
+            return self._fit_device(obs)
         return BaseHMM.fit(self, obs, **kwargs)
+
+    # ------------------------------------------------------------------ device-resident Baum-Welch
+    def _can_fit_on_device(self, obs):
+        import os
+        from .emission import (IndependentMultinomialAndGaussianEmissionModel,
+                               IndependentMultinomialEmissionModel)
+        em = self.emissionModel
+        if os.environ.get("TEHMM_DEVICE_EM", "1") == "0" or self.transMatEpsilons:
+            return False
+        if type(em) not in (IndependentMultinomialEmissionModel, IndependentMultinomialAndGaussianEmissionModel):
+            return False
+        if type(em) is IndependentMultinomialAndGaussianEmissionModel and self.trackList is None:
+            return False
+        return em.zeroAsMissingData is True and self.n_components < 64 and len(obs) > 0 and self._can_fuse(obs)
+
+    def _fit_device(self, tables):
+        """BaseHMM.fit (basehmm.py:475-541) with the observations, the sufficient statistics and the
+        parameters resident on the device: per iteration one fused E-step per batch (statistics ADDED
+        into one flat device buffer -- all-reduced over the ranks when torch.distributed is up), the
+        convergence test on the returned log-likelihood, and tehmm_model_mstep.  The host model is
+        refreshed at the end (every iteration with maxProb, whose bookkeeping deep-copies the model)."""
+        from . import dist as tdist
+        from .engine import DeviceStats, HipBatch
+        if self.algorithm not in ("viterbi", "map"):
+            self._algorithm = "viterbi"
+        self._init(tables, self.init_params)
+        arrays = [t.getNumPyArray() if isinstance(t, TrackTable) else np.ascontiguousarray(t)
+                  for t in tables]
+        ratios = [self.emissionModel.getSegmentRatios(t) for t in tables]
+        hm = self._device_model()
+        batches = []
+        for has_r in (True, False):
+            idx = [i for i, r in enumerate(ratios) if (r is not None) == has_r]
+            if not idx:
+                continue
+            lens = np.asarray([arrays[i].shape[0] for i in idx], dtype=np.int64)
+            offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            obs = np.concatenate([arrays[i] for i in idx], axis=0)
+            rcat = np.concatenate([ratios[i] for i in idx]) if has_r else None
+            batches.append((has_r, idx, HipBatch(obs, offs, rcat)))
+        stats = DeviceStats(hm)
+        gauss = self._gaussian_spec()
+        logprob = []
+        try:
+            for i in range(copy.deepcopy(self.n_iter)):
+                stats.zero()
+                seq_lp = np.zeros(len(tables))
+                for has_r, idx, hb in batches:
+                    hm.estep_device(hb, has_r, stats)
+                    seq_lp[idx] = hb.interval_logprobs()
+                if self.maxProb is True:
+                    self._pull_params(hm)
+                for lp in seq_lp:
+                    self._note_forward_logprob(float(lp))
+                tdist.allreduce_device_stats(stats)
+                curr_logprob = stats.head()[0]
+                logprob.append(curr_logprob)
+                logger.info("BW Iteration %d: LogProb %f" % (i, curr_logprob))
+                if i > 0 and abs(logprob[-1] - logprob[-2]) < self.thresh:
+                    break
+                if i == self.n_iter - 1:
+                    break
+                gp = hm.mstep(stats, "s" in self.params, "t" in self.params, "e" in self.params,
+                              1.0 if self.startprob_prior is None else self.startprob_prior,
+                              1.0 if self.transmat_prior is None else self.transmat_prior,
+                              self.emissionModel.fudge, gauss)
+                if gp is not None:
+                    for g, k in enumerate(gauss[0]):
+                        self.emissionModel.gaussParams[k] = gp[g]
+                self.current_iteration += 1
+        finally:
+            for _, _, hb in batches:
+                hb.close()
+            self._pull_params(hm)
+            stats.close()
+        self.validate()
+        return self
+
+    def _gaussian_spec(self):
+        """(track indices, values [n][S], uniform mix) of the gaussian tracks, or None."""
+        em = self.emissionModel
+        if not hasattr(em, "gaussParams") or self.trackList is None:
+            return None
+        tracks = [t for t in self.trackList if t.getDist() == "gaussian"]
+        if not tracks:
+            return None
+        S = em.logProbs.shape[2]
+        vals = np.zeros((len(tracks), S), dtype=np.float64)
+        for g, t in enumerate(tracks):
+            for sym in em.getTrackSymbols(t.getNumber()):
+                vals[g, sym] = float(t.getValueMap().getMapBack(sym))
+        return [t.getNumber() for t in tracks], vals, em.uniformMixProb
+
+    def _pull_params(self, hm):
+        """Host copy of the device-resident parameters (and the cache key that goes with them)."""
+        em = self.emissionModel
+        lt, pi, lp = hm.get_params(em.logProbs)
+        self._log_transmat, self._log_startprob, em.logProbs = lt, pi, lp
+        self._dev = ((lt.tobytes(), pi.tobytes(), lp.tobytes(), float(em.normalizeFac)), hm)
 
     # transmat / startprob keep exact zeros (-> -1e100), hmm.py:622-666
     def _get_transmat(self):
@@ -376,12 +512,13 @@ class MultitrackHmm(BaseHMM):
             self.emissionModel.getSegmentRatios(obs), np.ascontiguousarray(framelogprob))
         return logprob, state_sequence
 
-    def _note_forward_logprob(self, lp, whole_iteration=False):
-        """EM best-iteration bookkeeping of hmm.py:690-711 (quirk Q17)."""
-        if self.last_forward_log_prob_it != self.current_iteration or whole_iteration:
-            if self.maxProb is True and (self.current_iteration == 1 or (
-                    self.best_forward_log_prob is not None
-                    and self.last_forward_log_prob > self.best_forward_log_prob)):
+    def _note_forward_logprob(self, lp):
+        """EM best-iteration bookkeeping of hmm.py:690-711 (quirk Q17), called once per sequence in
+        sequence order.  The reference is Python 2, where `float > None` is True and `None > x` is
+        False: best_forward_log_prob starts as None and is seeded at the second iteration."""
+        if self.last_forward_log_prob_it != self.current_iteration:
+            if self.maxProb is True and (self.current_iteration == 1 or
+                                         _py2_gt(self.last_forward_log_prob, self.best_forward_log_prob)):
                 self.best_forward_log_prob = self.last_forward_log_prob
                 dev, self._dev = self._dev, None
                 self.bestCopy = copy.deepcopy(self)
@@ -395,7 +532,7 @@ class MultitrackHmm(BaseHMM):
         else:
             self.last_forward_log_prob += lp
             if self.maxProb is True and self.current_iteration > 1 and \
-                    self.last_forward_log_prob > self.best_forward_log_prob:
+                    _py2_gt(self.last_forward_log_prob, self.best_forward_log_prob):
                 self.best_forward_log_prob = self.last_forward_log_prob
                 dev, self._dev = self._dev, None
                 self.bestCopy = copy.deepcopy(self)
@@ -423,6 +560,15 @@ class MultitrackHmm(BaseHMM):
         d = dict(self.__dict__)
         d["_dev"] = None            # device handles are not picklable / copyable
         return d
+
+
+def _py2_gt(a, b):
+    """`a > b` with Python 2's ordering of None (None sorts below every number)."""
+    if a is None:
+        return False
+    if b is None:
+        return True
+    return a > b
 
 
 def _merge_results(res_a, res_b, mask):

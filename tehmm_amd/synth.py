@@ -16,6 +16,13 @@ from .common import myLog
 # config 2/3 of BASELINE.json: 8 multinomial + 2 gaussian tracks
 CONFIG2_SYMBOLS = (2, 2, 3, 4, 5, 8, 12, 30, 250, 250)
 CONFIG2_GAUSSIAN = (8, 9)
+# config 3b: the shape of data/mustang_alyrata_tracks_clean.xml -- 15 multinomial + 14 gaussian
+# (250 bins) + 3 binary tracks
+CONFIG3B_SYMBOLS = (2, 3, 3, 4, 4, 5, 6, 8, 8, 10, 12, 16, 20, 24, 30) + (250,) * 14 + (2, 2, 2)
+CONFIG3B_GAUSSIAN = tuple(range(15, 29))
+# config 4: 10 multinomial + 2 gaussian tracks
+CONFIG4_SYMBOLS = (2, 2, 3, 3, 4, 5, 8, 12, 20, 30, 250, 250)
+CONFIG4_GAUSSIAN = (10, 11)
 
 
 @dataclass
@@ -35,7 +42,10 @@ class SynthModel:
 
 def make_model(n_states: int, symbols_per_track: Sequence[int] = CONFIG2_SYMBOLS,
                gaussian_tracks: Sequence[int] = CONFIG2_GAUSSIAN, seed: int = 0,
-               sparse: float = 0.0, log_zero_emission: Optional[float] = None) -> SynthModel:
+               sparse: float = 0.0, log_zero_emission: Optional[float] = None,
+               stay: Optional[float] = None) -> SynthModel:
+    """stay: self-transition probability of every state (trained TE models sit at 0.99+); default: the
+    generator's A[i, i] += N, i.e. about 0.67 at N = 35."""
     rs = np.random.RandomState(seed)
     N = n_states
     K = len(symbols_per_track)
@@ -45,6 +55,13 @@ def make_model(n_states: int, symbols_per_track: Sequence[int] = CONFIG2_SYMBOLS
         mask = rs.rand(N, N) < sparse
         mask[np.arange(N), np.arange(N)] = False
         A[mask] = 0.0
+    if stay is not None and N > 1:
+        off = A.copy()
+        off[np.arange(N), np.arange(N)] = 0.0
+        rowsum = off.sum(axis=1, keepdims=True)
+        off = np.where(rowsum > 0, off / np.where(rowsum > 0, rowsum, 1.0) * (1.0 - stay), 0.0)
+        A = off
+        A[np.arange(N), np.arange(N)] = np.where(rowsum[:, 0] > 0, stay, 1.0)
     A /= A.sum(axis=1, keepdims=True)
     lt = np.asarray(myLog(A), dtype=np.float64)
     pi = np.full(N, 1.0 / N)

@@ -158,9 +158,12 @@ def test_driver_asymmetry_quirks():
 
 
 @pytest.mark.parametrize("with_ratio", [0, 1])
-def test_em_iteration_matches_reference(with_ratio):
+def test_em_iteration_matches_reference(with_ratio, monkeypatch):
     """One Baum-Welch iteration (E-step statistics and the parameters after the M-step) against
-    what the real reference computed on the same three sequences (one of length 1)."""
+    what the real reference computed on the same three sequences (one of length 1).  Host M-step
+    path (the statistics are inspected on the host); the device-resident loop is held to the same
+    fixture in tests/test_gpu_r2.py."""
+    monkeypatch.setenv("TEHMM_DEVICE_EM", "0")
     g = load_golden("em_iteration_r%d" % with_ratio)
     h, em = _golden_hmm(g, eff_len=(int(g["eff_len"]) if with_ratio else None), n_iter=2, thresh=0.0,
                         fixStart=False, fudge=0.0)

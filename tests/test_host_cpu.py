@@ -128,3 +128,98 @@ def test_synth_generators():
     assert lens.sum() == 10_000_000 and lens.min() >= 100_000 and lens.max() <= 2_000_000 + 100_000
     ms = synth.make_model(6, (3, 4), (), seed=7, sparse=0.6)
     assert (ms.log_transmat == -1e100).any()
+
+
+def test_maxprob_bookkeeping_python2_ordering():
+    """hmm.py:690-711 under Python 2: `float > None` is True, so best_forward_log_prob is seeded at the
+    second iteration and the best copy keeps following improvements (it used to stay None)."""
+    from tehmm_amd.emission import IndependentMultinomialEmissionModel
+    from tehmm_amd.hmm import MultitrackHmm, _py2_gt
+    assert _py2_gt(-5.0, None) and not _py2_gt(None, -5.0) and not _py2_gt(None, None)
+    h = MultitrackHmm(IndependentMultinomialEmissionModel(2, [2]), maxProb=True)
+    # three iterations, two sequences each; iteration totals -100, -90, -95
+    per_iter = [(-60.0, -40.0), (-50.0, -40.0), (-55.0, -40.0)]
+    marks = []
+    for it, lps in enumerate(per_iter, start=1):
+        h.current_iteration = it
+        for lp in lps:
+            h._note_forward_logprob(lp)
+        marks.append((h.best_forward_log_prob, h.bestCopy.current_iteration if h.bestCopy else None))
+    # iteration 1: best = None (the copy exists); iteration 2: first sequence seeds best with iteration 1's
+    # total (-100), the second sequence's partial-sum test (-90 > -100) moves it to -90 (the reference's
+    # "very ugly" repeat); iteration 3: -90 (previous total) is not > -90 and -95 is not either
+    assert marks[0] == (None, 1)
+    assert marks[1] == (-90.0, 2)
+    assert marks[2] == (-90.0, 2)
+    assert h.last_forward_log_prob == -95.0 and h.last_forward_log_prob_it == 3
+
+
+def test_native_bed_writer(tmp_path):
+    """tehmm_write_bed is host code (no GPU): the lines of teHmmEval.statesToBed, Python-2 float text."""
+    from tehmm_amd import output
+    starts = np.asarray([10, 20, 35], dtype=np.int64)
+    ends = np.asarray([20, 35, 36], dtype=np.int64)
+    p = tmp_path / "a.bed"
+    output._write(str(p), False, "chr2", starts, ends, states=[2, 0, 1], names=["LTR", "Outside", "TSD"])
+    assert p.read_text() == "chr2\t10\t20\tTSD\nchr2\t20\t35\tLTR\nchr2\t35\t36\tOutside\n"
+    output._write(str(p), True, "chr2", starts[:1], ends[:1], states=[7])
+    assert p.read_text().endswith("chr2\t10\t20\t7\n")
+    q = tmp_path / "b.bed"
+    vals = [1.0, 0.651120311022880, 1.5e-07]
+    output._write(str(q), False, "c", starts, ends, values=vals)
+    cols = [ln.split("\t")[3] for ln in q.read_text().strip().split("\n")]
+    assert cols == ["1.0", "0.651120311023", "1.5e-07"]      # str(float) of Python 2: '%.12g' (+ '.0')
+
+
+def test_category_map_and_overlap():
+    from tehmm_amd.track import CategoryMap, IntegerTrackTable
+    m = CategoryMap(reserved=2)
+    assert [m.getMap(x, update=True) for x in ("b", "a", "b", "c")] == [2, 3, 2, 4]
+    assert m.getMap("zzz") == m.getMissingVal() == 1 and len(m) == 4
+    m.sort()
+    assert [m.getMap(x) for x in ("a", "b", "c")] == [2, 3, 4] and m.getMapBack(3) == "b"
+    g = CategoryMap(reserved=1, defaultVal="0", scale=0.1)
+    assert g.getMap(57.0, update=True) == 2 and g.getMap(51.0) == 2 and g.getMapBack(2) == 50.0
+    assert g.getMapBack(99) == 0.0                       # unknown symbol -> the default value
+    tab = IntegerTrackTable(1, "c", 100, 200)
+    assert tab.getOverlapInTableCoords(("c", 50, 120, 3)) == ["c", 0, 20, 3]
+    assert tab.getOverlapInTableCoords(("c", 200, 220, 3)) is None
+    assert tab.getOverlapInTableCoords(("d", 100, 120, 3)) is None
+    seg = IntegerTrackTable(1, "c", 100, 200).setData(np.ones((4, 1), dtype=np.uint8))
+    seg.setSegmentOffsets([0, 10, 30, 90])
+    assert seg.getOverlapInTableCoords(("c", 105, 131, 1)) == ["c", 0, 3, 1]
+    assert seg.getOverlapInTableCoords(("c", 110, 130, 1)) == ["c", 1, 2, 1]
+    assert seg.getOverlapInTableCoords(("c", 195, 400, 1)) == ["c", 3, 4, 1]
+
+
+def test_oracle_under_address_sanitizer():
+    """The CPU oracle rebuilt with -fsanitize=address (oracle/Makefile: `make asan`) runs a ragged batch
+    clean (GPU sanitizers are not available on the pool; the checker at least is memory-clean)."""
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.check_call(["make", "-s", "-C", odir, "asan"])
+    libasan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(libasan) or not os.path.exists(libasan):
+        pytest.skip("libasan not available")
+    code = r'''
+import ctypes, numpy as np, sys
+sys.path.insert(0, %r)
+from tehmm_amd import synth
+lib = ctypes.CDLL(%r)
+m = synth.make_model(7, (3, 4), (), seed=1)
+lens = [1, 2, 130, 65]
+offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+obs = synth.sample_obs(m, int(offs[-1]), seed=2, missing=0.05)
+K, N, S = m.log_probs.shape
+paths = np.zeros(int(offs[-1]), dtype=np.int64); vlp = np.zeros(4); flp = np.zeros(4)
+post = np.zeros((int(offs[-1]), N))
+P = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t))
+rc = lib.oracle_eval_batch(4, P(offs, ctypes.c_int64), K, N, S, P(obs, ctypes.c_uint8),
+    P(np.ascontiguousarray(m.log_probs), ctypes.c_double), ctypes.c_double(1.0),
+    P(m.log_startprob, ctypes.c_double), P(np.ascontiguousarray(m.log_transmat), ctypes.c_double), None,
+    P(paths, ctypes.c_int64), P(vlp, ctypes.c_double), P(flp, ctypes.c_double), P(post, ctypes.c_double), 2)
+assert rc == 0 and np.isfinite(vlp).all() and abs(post.sum(axis=1) - 1).max() < 1e-9
+print("ASAN_OK")
+''' % (ROOT, os.path.join(odir, "libtehmm_oracle_asan.so"))
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and "ASAN_OK" in out.stdout, out.stdout + out.stderr
