@@ -309,6 +309,40 @@ __global__ void k_model_ltab(MstepTracks tr, const int *ldsbase, int NP, const d
     ltab[(int64_t)ldsbase[k] * NP + i] = tab[(int64_t)tr.rowbase[k] * NP + i];
 }
 
+// Table rows of the fused forward / backward passes (tehmm_fused.hip.h): row r of tab [NP] (log) ->
+// ptab [r][4][KSP]: quarter kq holds the states kq, kq + 4, ... and, in its last slot, the row's scale
+// c = max_j tab[r][j];  entries are exp(tab - c) (log_domain: the log values themselves, slot unused).
+// ldsrow[r] >= 0: the row is also written to the LDS-staged copy at that index.
+__global__ void k_build_ptab(int R1, int N, int NP, int KSP, const double *tab, int log_domain, double *ptab) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R1) return;
+  const double *row = tab + (int64_t)r * NP;
+  double c = -INFINITY;
+  for (int j = 0; j < N; ++j) c = fmax(c, row[j]);
+  const bool dead = !(c > -INFINITY);
+  double *o = ptab + (int64_t)r * 4 * KSP;
+  const int KS = NP / 4;
+  for (int kq = 0; kq < 4; ++kq) {
+    for (int s = 0; s < KSP; ++s) {
+      const int j = kq + 4 * s;
+      double v = 0.0;
+      if (s < KS && j < N) v = log_domain ? row[j] : (dead ? 0.0 : exp(row[j] - c));
+      else if (s < KS && log_domain) v = -INFINITY;
+      else if (s == KS) v = (log_domain || dead) ? 0.0 : c;
+      o[kq * KSP + s] = v;
+    }
+  }
+}
+__global__ void k_pack_ptab_lds(int K, const int *rowbase, const int *rowcnt, const int *ldsbase, int lds_zero,
+                                int zero_row, int ROW_D, const double *ptab, double *ptab_lds) {
+  const int k = blockIdx.x;          // block K: the zero row
+  int src, dst, cnt;
+  if (k == K) { src = zero_row; dst = lds_zero; cnt = 1; }
+  else { if (ldsbase[k] < 0) return; src = rowbase[k]; dst = ldsbase[k]; cnt = rowcnt[k]; }
+  for (int i = threadIdx.x; i < cnt * ROW_D; i += blockDim.x)
+    ptab_lds[(int64_t)dst * ROW_D + i] = ptab[(int64_t)src * ROW_D + i];
+}
+
 // sum of the per-interval forward log-likelihoods (interval order) into stats[0], count into stats[1]
 __global__ void k_stats_logprob(int n, const int *ids, const double *fwd_lp, double *stats) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {

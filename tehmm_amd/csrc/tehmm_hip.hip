@@ -5,6 +5,7 @@
 #include "tehmm_coop.hip.h"
 #include "tehmm_lane.hip.h"
 #include "tehmm_aux.hip.h"
+#include "tehmm_fused.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -110,6 +111,11 @@ struct tehmm_model {
   DBuf<double> lt, ltT, A, AT, pi, tab, ltab;
   DBuf<double> ltG, AG, ATG;   // output-group-major copies for the lane = item kernels (tehmm_lane.hip.h)
   DBuf<float> ltP;             // float pairs [o / 2][f][o % 2] for the packed P0 pass
+  // emission tables of the fused lane passes (tehmm_fused.hip.h): [(R + 1)][4][KSP] + the LDS-staged copy
+  DBuf<double> ptab, ptab_lds;
+  DBuf<int> d_rowinfo;         // rowbase[K] | rowcnt[K] | ldsbase[K] on the device
+  int KSP = 0;
+  bool ptab_log = false;       // log-domain rows (normalizeFac != 1): the product form does not apply
   int rowbase[TEHMM_MAX_TRACKS];
   int rowcnt[TEHMM_MAX_TRACKS];
   int ldsbase[TEHMM_MAX_TRACKS];
@@ -150,6 +156,7 @@ struct LaneWork {
   DBuf<double> glog_f, cpre_f, dl_f, lr_f, dl_b;
   DBuf<int64_t> item_t0, ifirst;
   DBuf<double> B, BH, MS, AL, BE, pre_f, end_f, pre_b, end_b, slog32;
+  DBuf<double> chk;           // fused passes: speculative beta rows at the chain's check positions
   // Viterbi lane passes
   DBuf<double> vpre, vend, vgain, vtierows, vpiecemin, qtabs;
   DBuf<float> B32;
@@ -391,6 +398,30 @@ int tehmm_update_counts_i32(int64_t T, int K, int N, int S, const int32_t *obs, 
 // ------------------------------------------------------------------------------------------
 // model / batch handles
 // ------------------------------------------------------------------------------------------
+// (Re)build the fused passes' emission tables from m->tab (model creation, M-step).
+static int build_ptab(tehmm_model *m) {
+  if (m->NP > 36) return TEHMM_OK;              // the lane passes are instantiated up to 36 padded states
+  const int KS = m->NP / 4, KSP = ((KS + 1) + 1) & ~1, ROW_D = 4 * KSP, K = m->K;
+  m->KSP = KSP;
+  m->ptab_log = m->normalize != 1.0;
+  if (!m->ptab.p) {
+    HIPCHK(m->ptab.alloc((size_t)(m->R + 1) * ROW_D));
+    HIPCHK(m->ptab_lds.alloc((size_t)std::max(1, m->lds_rows) * ROW_D));
+    std::vector<int> info((size_t)3 * K);
+    for (int k = 0; k < K; ++k) { info[k] = m->rowbase[k]; info[K + k] = m->rowcnt[k]; info[2 * K + k] = m->ldsbase[k]; }
+    HIPCHK(m->d_rowinfo.upload(info.data(), info.size()));
+  }
+  hipLaunchKernelGGL(k_build_ptab, dim3(grid_for(m->R + 1, 64)), dim3(64), 0, 0, m->R + 1, m->N, m->NP, KSP,
+                     (const double *)m->tab.p, m->ptab_log ? 1 : 0, m->ptab.p);
+  if (m->lds_rows > 0)
+    hipLaunchKernelGGL(k_pack_ptab_lds, dim3(K + 1), dim3(256), 0, 0, K, (const int *)m->d_rowinfo.p,
+                       (const int *)m->d_rowinfo.p + K, (const int *)m->d_rowinfo.p + 2 * K, m->lds_zero, m->R, ROW_D,
+                       (const double *)m->ptab.p, m->ptab_lds.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
+  return TEHMM_OK;
+}
+
 int tehmm_model_create(int N, int K, int S, const double *lt, const double *pi,
                        const double *logProbs, double normalize, const int32_t *symbolsPerTrack,
                        tehmm_model_t **out) {
@@ -489,6 +520,10 @@ int tehmm_model_create(int N, int K, int S, const double *lt, const double *pi,
   if (e != hipSuccess) {
     delete m;
     return fail(TEHMM_ERR_HIP, std::string("tehmm_model_create: ") + hipGetErrorString(e));
+  }
+  if (int rc = build_ptab(m)) {
+    delete m;
+    return rc;
   }
   *out = m;
   return TEHMM_OK;
@@ -865,7 +900,7 @@ static int lane_sub_size(int CS, int64_t total) {
 }
 
 static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, bool want_fb, bool want_vit,
-                        bool want_gain) {
+                        bool want_gain, bool fused_fb) {
   LaneWork &lw = b->lw;
   if (lw.L != L || lw.CS != CS || lw.NP != m->NP || !lw.item_iv.p) {
     std::vector<int> h_iv;
@@ -879,7 +914,7 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
     }
     h_first[b->n] = (int64_t)h_iv.size();
     for (DBuf<double> *d : {&lw.B, &lw.BH, &lw.MS, &lw.AL, &lw.BE, &lw.pre_f, &lw.end_f, &lw.pre_b, &lw.end_b,
-                            &lw.slog32, &lw.vpre, &lw.vend, &lw.vgain, &lw.vtierows, &lw.vpiecemin})
+                            &lw.slog32, &lw.vpre, &lw.vend, &lw.vgain, &lw.vtierows, &lw.vpiecemin, &lw.chk})
       d->release();
     for (DBuf<int> *d : {&lw.ok_f, &lw.ok_b, &lw.vbad, &lw.vntie, &lw.vties, &lw.link_f, &lw.link_b, &lw.runend_f,
                          &lw.runstart_b})
@@ -904,7 +939,6 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
   const size_t vecs = (size_t)std::max(1, lw.n_groups) * 64 * m->NP;
   if (want_fb && !lw.AL.p) {
     HIPCHK(lw.AL.alloc(rows * m->NP));
-    HIPCHK(lw.BE.alloc(rows * m->NP));
     HIPCHK(lw.pre_f.alloc(vecs));
     HIPCHK(lw.end_f.alloc(vecs));
     HIPCHK(lw.pre_b.alloc(vecs));
@@ -920,7 +954,10 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
     HIPCHK(lw.lr_f.alloc((size_t)std::max(1, lw.n_groups) * 64));
     HIPCHK(lw.dl_b.alloc((size_t)std::max(1, lw.n_groups) * 64));
   }
-  if (want_fb && !lw.BH.p) {
+  if (want_fb && fused_fb && !lw.chk.p)
+    HIPCHK(lw.chk.alloc((size_t)std::max(1, lw.n_groups) * 64 * (size_t)(L / 64) * m->NP));
+  if (want_fb && !fused_fb && !lw.BH.p) {
+    HIPCHK(lw.BE.alloc(rows * m->NP));
     HIPCHK(lw.BH.alloc(rows * m->NP));
     if (!lw.MS.p) HIPCHK(lw.MS.alloc(rows));
   }
@@ -1097,6 +1134,65 @@ static void launch_fb_lane(tehmm_batch *b, const tehmm_model *m, const IntervalT
   (void)hipStreamWaitEvent(st, b->evX[1], 0);
 }
 
+// Fused posterior pipeline (tehmm_fused.hip.h), one stream: forward lane pass -> forward links / runs / exact
+// chain (alpha' rows final) -> backward lane pass writing the posterior rows -> backward links / runs ->
+// [ev_mid] -> backward exact chain (posterior rows of its exact blocks).  ev_fwd: end of the forward half.
+template <int NT>
+static void launch_fused_fb(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em_in,
+                            const FbChunks &fc, int Wu, hipStream_t st, hipEvent_t ev_fwd, hipEvent_t ev_mid) {
+  LaneWork &lw = b->lw;
+  const LaneGeom lg = lane_geom(lw);
+  const dim3 gridm((unsigned)lw.n_groups);           // 4 tiles of 16 items per 256-thread block = one group
+  const dim3 gridc((fc.n + 255) / 256);              // one thread per chunk
+  const dim3 gridit((lw.n_items + 255) / 256);       // one thread per item
+  const dim3 gridi(std::max(1, b->n));
+  const char *er = std::getenv("TEHMM_FB_RUNS");
+  const int extend = (er && std::atoi(er) == 0) ? 0 : 1;
+  FusedTab ft;
+  ft.ptab = m->ptab.p;
+  ft.ptab_lds = m->ptab_lds.p;
+  const EmisTab emc = b->n > 256 ? without_lds_tables(em_in) : em_in;          // the chains' own emission rows
+  const size_t lds_f = (size_t)em_in.lds_rows * FusedGeom<NT>::ROW_D * sizeof(double);
+  const size_t lds_c = ((size_t)2 * 64 * (NT + 1) + 2 * 64 + NT + (size_t)emc.lds_rows * NT + 8) * sizeof(double);
+  allow_lds(k_fb_fix<NT, 0, false, true>, lds_c);
+  allow_lds(k_fb_fix<NT, 1, false, true, true>, lds_c);
+#define TEHMM_FUSED_LAUNCH(LOG_)                                                                                     \
+  do {                                                                                                              \
+    allow_lds(k_fused_fwd<NT, LOG_>, lds_f);                                                                         \
+    allow_lds(k_fused_bwd<NT, LOG_, true>, lds_f);                                                                   \
+    hipLaunchKernelGGL((k_fused_fwd<NT, LOG_>), gridm, dim3(256), lds_f, st, iv, em_in, ft, lg, m->N, fc.CS, Wu,     \
+                       (const double *)m->A.p, lw.AL.p, lw.pre_f.p, lw.end_f.p, lw.slog32.p);                        \
+    hipLaunchKernelGGL((k_fb_itemlinks<NT>), gridit, dim3(256), 0, st, lg, m->N, lw.pre_f.p, lw.end_f.p,             \
+                       lw.pre_b.p, lw.end_b.p, lw.dl_f.p, lw.lr_f.p, lw.dl_b.p, 1);                                  \
+    hipLaunchKernelGGL((k_fb_stitch<NT>), gridc, dim3(256), 0, st, iv, lg, fc, m->N, lw.slog32.p, lw.end_b.p,        \
+                       lw.dl_f.p, lw.lr_f.p, lw.dl_b.p, lw.ok_f.p, lw.ok_b.p, 1);                                    \
+    hipLaunchKernelGGL(k_fb_runs, gridi, dim3(64), 0, st, iv, fc, (const int *)lw.ok_f.p, (const int *)lw.ok_b.p,    \
+                       extend, 1);                                                                                   \
+    hipLaunchKernelGGL((k_fb_fix<NT, 0, false, true>), dim3(b->n), dim3(128), lds_c, st, iv, emc, fc, m->N, m->A.p,   \
+                       m->lt.p, m->pi.p, (const double *)nullptr, lw.AL.p, b->fwd_lp.p, b->dead.p,                   \
+                       (double *)nullptr, (int *)nullptr, 1, b->sw.stats.p, lg, (const int *)lw.ok_f.p,              \
+                       (const double *)nullptr, (double *)nullptr);                                                  \
+    (void)hipEventRecord(ev_fwd, st);                                                                                \
+    hipLaunchKernelGGL((k_fused_bwd<NT, LOG_, true>), gridm, dim3(256), lds_f, st, iv, em_in, ft, lg, m->N, fc.CS,    \
+                       Wu, (const double *)m->A.p, (const double *)lw.AL.p, b->post.p, lw.pre_b.p, lw.end_b.p,       \
+                       lw.chk.p);                                                                                    \
+  } while (0)
+  if (m->ptab_log) TEHMM_FUSED_LAUNCH(true);
+  else TEHMM_FUSED_LAUNCH(false);
+#undef TEHMM_FUSED_LAUNCH
+  hipLaunchKernelGGL((k_fb_itemlinks<NT>), gridit, dim3(256), 0, st, lg, m->N, lw.pre_f.p, lw.end_f.p, lw.pre_b.p,
+                     lw.end_b.p, lw.dl_f.p, lw.lr_f.p, lw.dl_b.p, 2);
+  hipLaunchKernelGGL((k_fb_stitch<NT>), gridc, dim3(256), 0, st, iv, lg, fc, m->N, lw.slog32.p, lw.end_b.p,
+                     lw.dl_f.p, lw.lr_f.p, lw.dl_b.p, lw.ok_f.p, lw.ok_b.p, 2);
+  hipLaunchKernelGGL(k_fb_runs, gridi, dim3(64), 0, st, iv, fc, (const int *)lw.ok_f.p, (const int *)lw.ok_b.p,
+                     extend, 2);
+  (void)hipEventRecord(ev_mid, st);
+  hipLaunchKernelGGL((k_fb_fix<NT, 1, false, true, true>), dim3(b->n), dim3(128), lds_c, st, iv, emc, fc, m->N, m->A.p,
+                     m->lt.p, m->pi.p, (const double *)nullptr, lw.AL.p, b->fwd_lp.p, b->dead.p,
+                     (double *)nullptr, (int *)nullptr, 1, b->sw.stats.p, lg, (const int *)lw.ok_b.p,
+                     (const double *)lw.chk.p, b->post.p);
+}
+
 template <int NT>
 static void launch_combine_lane(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, hipStream_t st) {
   LaneWork &lw = b->lw;
@@ -1186,15 +1282,21 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   // The lane = item Viterbi passes (TEHMM_LANE_VIT, default on) additionally need the fp64 log rows.
   const char *lvs = std::getenv("TEHMM_LANE_VIT");
   bool want_vlane = !(lvs && std::atoi(lvs) == 0);
+  // TEHMM_FUSED=0 selects the round-1 posterior pipeline (emission rows, alpha' and beta' through HBM,
+  // separate combine); default: the fused passes of tehmm_fused.hip.h
+  const char *fus = std::getenv("TEHMM_FUSED");
+  const bool fused_fb = !(fus && std::atoi(fus) == 0) && m->ptab.p != nullptr;
   if (LS > 0 && !b->lw.AL.p && !b->lw.B.p && !b->lw.B32.p) {
-    // the item-interleaved buffers (emission rows in up to three forms, alpha', beta': 8 * NP bytes per
-    // position each, 4 * NP for the float rows) must fit next to the results; otherwise do without the
-    // fp64 log rows, and failing that stay with the [T][N] speculative passes
+    // the item-interleaved buffers (8 * NP bytes per position each: alpha' -- plus, without the fused
+    // passes, beta' and the linear emission rows --, the fp64 log rows of the exact Viterbi pass; 4 * NP
+    // for the float rows of P0) must fit next to the results; otherwise do without the fp64 log rows, and
+    // failing that stay with the [T][N] speculative passes
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     const double per = (double)b->total * m->NP * 8.0;
-    b->lw.no_vlane = per * 5.7 > 0.85 * (double)free_b;
-    if (per * 4.7 > 0.85 * (double)free_b) LS = 0;
+    const double fb_units = fspec ? (fused_fb ? 1.1 : 3.2) : 0.0, p0_units = vspec ? 0.5 : 0.0;
+    b->lw.no_vlane = per * (fb_units + p0_units + 1.0) > 0.85 * (double)free_b;
+    if (per * (fb_units + p0_units) > 0.85 * (double)free_b) LS = 0;
   }
   if (LS > 0 && want_vlane && !b->lw.no_vlane && !b->lw.B.p && (b->lw.AL.p || b->lw.B32.p)) {
     // workspaces of an earlier call exist already: the fp64 (+ float) log rows must still fit
@@ -1216,7 +1318,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   std::vector<double> &gain = lw.hs_gain;
   if (vit) (void)hipEventRecord(b->ev[eV], b->sV);
   if (vlane || flane || glane) {
-    rc = lane_prepare(b, m, CS, LS, flane, vlane, glane);
+    rc = lane_prepare(b, m, CS, LS, flane, vlane, glane, fused_fb);
     if (rc) return rc;
   }
   // Scheduling.  The speculative Viterbi passes, the emission rows, the forward / backward lane passes
@@ -1231,7 +1333,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   if (vlane || glane) {
     // emission rows of every position, once, item-interleaved (log rows for Viterbi, linear for fwd/bwd)
     hipStream_t st = b->sV;
-#define CALL(NT_) launch_emis_lane<NT_>(b, m, iv, em, vlane, flane, glane, st)
+#define CALL(NT_) launch_emis_lane<NT_>(b, m, iv, em, vlane, flane && !fused_fb, glane, st)
     TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
     (void)hipEventRecord(b->ev[eV + 4], st);
@@ -1263,7 +1365,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     }
   }
   auto enqueue_emission = [&]() {
-    if (flane && !vlane && !glane) {
+    if (flane && !fused_fb && !vlane && !glane) {
       // emission rows (linear domain) for the forward / backward lane passes
       hipStream_t st = b->sP;
 #define CALL(NT_) launch_emis_lane<NT_>(b, m, iv, em, false, true, false, st)
@@ -1285,13 +1387,19 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       fc.pre_f = lw.cpre_f.p; fc.runstart_b = lw.runstart_b.p;
       (void)hipMemsetAsync(b->dead.p, 0, (size_t)(b->n + 1) * sizeof(int), st);
       (void)hipMemsetAsync(sw.stats.p + 2, 0, 4 * sizeof(int), st);
+      if (fused_fb) {
+#define CALL(NT_) launch_fused_fb<NT_>(b, m, iv, em, fc, WuF, st, b->ev[eP + 3], b->ev[eP + 1])
+        TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+      } else {
 #define CALL(NT_) launch_fb_lane<NT_>(b, m, iv, em, fc, WuF, st, b->ev[eP + 3])
-      TEHMM_NT_DISPATCH(m->NP, CALL)
+        TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
-      (void)hipEventRecord(b->ev[eP + 1], st);
+        (void)hipEventRecord(b->ev[eP + 1], st);
 #define CALL(NT_) launch_combine_lane<NT_>(b, m, iv, st)
-      TEHMM_NT_DISPATCH(m->NP, CALL)
+        TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
+      }
       hipLaunchKernelGGL(k_poison_dead, dim3(64, std::min(b->n, 1024)), dim3(256), 0, st, iv, b->dead.p, m->N,
                          b->post.p, b->fwd_lp.p);
     } else if (fspec) {
@@ -1510,7 +1618,12 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     b->tpairs.push_back({eV + 1, eV + 2});
   }
   if (postr) {
-    if (flane) {
+    if (flane && fused_fb) {
+      b->tnames.push_back("forward_pass");               // lane pass + links + exact forward chain
+      b->tpairs.push_back({10, eP + 3});
+      b->tnames.push_back("backward_posterior_pass");    // lane pass incl. the posterior rows + links
+      b->tpairs.push_back({eP + 3, eP + 1});
+    } else if (flane) {
       if (!vlane && !glane) {
         b->tnames.push_back("emission_rows");
         b->tpairs.push_back({eP, eP + 4});
@@ -1528,7 +1641,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       b->tnames.push_back(coop ? "forward_backward" : "forward");
       b->tpairs.push_back({eP, eP + 1});
     }
-    b->tnames.push_back(coop ? "posterior_combine" : "backward_posterior");
+    b->tnames.push_back(flane && fused_fb ? "backward_chain" : (coop ? "posterior_combine" : "backward_posterior"));
     b->tpairs.push_back({eP + 1, eP + 2});
   }
   HIPCHK(hipGetLastError());

@@ -613,12 +613,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // ------------------------------------------------------------------------------------------
 // LANE: `rows` is item-interleaved (tehmm_lane.hip.h) and okc[c] tells whether the chunk's item links
 // hold; otherwise rows is [T][N] as written by k_fb_spec.
-template <int NT, int DIR, bool TRATIO, bool LANE>
+// FUSED (backward, with the fused lane passes of tehmm_fused.hip.h): `rows` holds the alpha' rows
+// (read only); the speculative beta rows exist only at the check positions (chk [item][L / 64][NT]) and the
+// chain writes the posterior rows normalise(alpha' * beta) of its exact blocks (+ eps quirk) to post.
+template <int NT, int DIR, bool TRATIO, bool LANE, bool FUSED = false>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A, const double *g_lt,
               const double *g_pi, const double *tratios, double *rows, double *fwd_logprob,
               int *dead_flag, double *wrows, int *escale, int allow_jump, int *stats, LaneGeom lg,
-              const int *okc) {
+              const int *okc, const double *chk = nullptr, double *post = nullptr) {
   extern __shared__ double sm[];
   constexpr int RS = NT + 1;
   constexpr int CPB = 64;
@@ -716,7 +719,12 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
       }
       const int64_t target = DIR == 0 ? fc.t0[cj] + fc.CS : fc.t0[cj];      // key of the block after a jump
       double srow = 0.0;
-      if (spec) srow = live ? brow[(tg - lo) * rstride] : 0.0;  // speculative row, before overwriting
+      if (spec) {                                               // speculative row, before overwriting
+        if (FUSED && DIR == 1)
+          srow = live ? chk[((ifirst + tg / lg.L) * (lg.L / 64) + (tg % lg.L) / 64) * NT + jl] : 0.0;
+        else
+          srow = live ? brow[(tg - lo) * rstride] : 0.0;
+      }
       else if (lane == 0) {
         seqpos[(it + 1) & 3] = DIR == 0 ? cur + np : lo;
         *gen = it + 1;
@@ -758,7 +766,11 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
             const int e = ((__builtin_amdgcn_readlane(__double2hiint(ssum), NT - 1) >> 20) & 0x7ff) - 1022;
             bt = live ? ldexp(ssum, -e) : 0.0;
           }
-          if (live) brow[p * rstride] = bt;
+          if (FUSED) {
+            if (lane < NT) const_cast<double *>(br)[p * RS + lane] = bt;      // (the bh slot of this step is free)
+          } else if (live) {
+            brow[p * rstride] = bt;
+          }
           if (spec && q == pg) {
             const double d = proj_dist(bt, srow, live, rho);
             jump = d <= TEHMM_FB_TOL;
@@ -772,6 +784,18 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
           jump = d <= TEHMM_FB_TOL;
           Sg = Ecum * 0.6931471805599453 + Mcum;
           if (lane == 0) { seqpos[(it + 1) & 3] = jump ? target : cur + np; *gen = it + 1; }
+        }
+      }
+      if (FUSED && DIR == 1) {
+        // posterior rows of this exact block: lane = state, one wave reduction per row
+        const double eps = 1.1920928955078125e-07;
+        const double inv_epsden = 1.0 / (1.0 + (double)N * eps);
+        double *po = post + (iv.out0[id] + lo) * N;
+        for (int p = 0; p < np; ++p) {
+          const double a = live ? brow[p * rstride] : 0.0;
+          const double g = a * (live ? br[p * RS + lane] : 0.0);
+          const double tot = wave_sum_f64(g);
+          if (live) po[(int64_t)p * N + lane] = (g / tot + eps) * inv_epsden;
         }
       }
       if (jump) {
