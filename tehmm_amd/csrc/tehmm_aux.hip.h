@@ -333,14 +333,17 @@ __global__ void k_build_ptab(int R1, int N, int NP, int KSP, const double *tab, 
     }
   }
 }
+// (rows of the LDS copy are ROW_L >= ROW_D doubles apart: bank spreading, see FusedGeom)
 __global__ void k_pack_ptab_lds(int K, const int *rowbase, const int *rowcnt, const int *ldsbase, int lds_zero,
-                                int zero_row, int ROW_D, const double *ptab, double *ptab_lds) {
+                                int zero_row, int ROW_D, int ROW_L, const double *ptab, double *ptab_lds) {
   const int k = blockIdx.x;          // block K: the zero row
   int src, dst, cnt;
   if (k == K) { src = zero_row; dst = lds_zero; cnt = 1; }
   else { if (ldsbase[k] < 0) return; src = rowbase[k]; dst = ldsbase[k]; cnt = rowcnt[k]; }
-  for (int i = threadIdx.x; i < cnt * ROW_D; i += blockDim.x)
-    ptab_lds[(int64_t)dst * ROW_D + i] = ptab[(int64_t)src * ROW_D + i];
+  for (int i = threadIdx.x; i < cnt * ROW_L; i += blockDim.x) {
+    const int r = i / ROW_L, c = i - r * ROW_L;
+    ptab_lds[(int64_t)(dst + r) * ROW_L + c] = c < ROW_D ? ptab[(int64_t)(src + r) * ROW_D + c] : 0.0;
+  }
 }
 
 // sum of the per-interval forward log-likelihoods (interval order) into stats[0], count into stats[1]

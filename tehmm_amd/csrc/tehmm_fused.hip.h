@@ -33,12 +33,40 @@ struct FusedGeom {
   static constexpr int KSP = ((KS + 1) + 1) & ~1;         // slice length in doubles (>= KS + 1, even)
   static constexpr int RT = (NT + 15) / 16;               // row tiles of the product
   static constexpr int SLICE_B = KSP * 8;                 // bytes per (row, quarter)
-  static constexpr int ROW_D = 4 * KSP;                   // doubles per table row
+  static constexpr int ROW_D = 4 * KSP;                   // doubles per table row (global copy)
+  // LDS copy: rows are 2 doubles further apart, so that consecutive rows start 4 banks x an odd number
+  // apart (8 KSP + 4 dwords = 4 mod 8): 16 lanes gathering 16 different rows spread over all 64 banks
+  // instead of piling up on 4 (a 320-byte stride is 16 banks mod 64)
+  static constexpr int ROW_D_LDS = 4 * KSP + 2;
 };
 
+// What the fused passes read besides the transition table:
+//   * rixx: the observation rows ALREADY TRANSLATED to table-row indices (k_fused_rowindex, once per batch,
+//     model and lane geometry), one uint16 per track in processing order -- the first n_glb entries of a row
+//     are rows of the global table ptab (tracks too large for LDS, served from L2), the rest rows of the LDS
+//     copy; a symbol beyond its track's range points at the all-ones (log: zeros) row.  With the indices
+//     precomputed a step needs no per-track metadata (the first version read rowcnt / rowbase / ldsbase of
+//     every track from the kernel-argument segment: 20 scalar loads and waits per position).
+//     Layout: per 16-item tile and per block of SB steps one contiguous 3 KB record
+//         [tile][block][step in block][word][item in tile]   (uint64 words of four indices)
+//     over the item's EXTENDED range of L + 2 Wu steps (position t0 - Wu + e, clamped to the interval), so
+//     that both passes find their warm-up positions in their own record.  A wave copies the record of its
+//     next block into LDS with three coalesced 16-byte loads per lane, one block (>= 3 steps) ahead: the
+//     index words are then LDS reads, and no wait of the step loop is ever for a stream load (vector-memory
+//     waits complete in issue order: a wait for a fresh 8-byte read 12 KB away from its neighbour's, behind the
+//     previous step's stores, cost ~2 000 cycles three times per step in the version that read them directly).
+//   * ptab / the LDS copy: rows [4][KSP] as described above.
+#define TEHMM_FUSED_BLKW 24      // index words per (item, block): SB = 24 / FKW steps per block
+
 struct FusedTab {
+  const unsigned long long *rixx;   // [tiles][NB][SB][FKW][16]
   const double *ptab;       // [(R + 1)][4][KSP] linear (or log, LOGDOM) rows + scale slot, global
-  const double *ptab_lds;   // [lds_rows][4][KSP] the LDS-staged rows, packed like EmisTab::ltab_src
+  const double *ptab_lds;   // [lds_rows][ROW_D_LDS] the LDS-staged rows
+  int FKW;                  // index words per position: ceil(K / 4) rounded up to a divisor of 24
+  int SB, NB;               // steps per block, blocks per item (extended range)
+  int K, n_glb;             // tracks; the first n_glb of the processing order come from ptab
+  int lds_rows;
+  double normalize;         // LOGDOM only
 };
 
 // the slice of table row `row` for this lane's quarter: KSP doubles into x[]
@@ -46,7 +74,7 @@ template <int NT>
 __device__ __forceinline__ void fused_load_lds(const double *lds, int row, int kq, double (&x)[FusedGeom<NT>::KSP]) {
   using G = FusedGeom<NT>;
   lds_cd2 *p = (lds_cd2 *)(size_t)((unsigned)(size_t)(__attribute__((address_space(3))) const double *)lds +
-                                   (unsigned)((row * 4 + kq) * G::SLICE_B));
+                                   (unsigned)(row * (G::ROW_D_LDS * 8) + kq * G::SLICE_B));
 #pragma unroll
   for (int i = 0; i < G::KSP / 2; ++i) {
     const d2v v = p[i];
@@ -66,75 +94,244 @@ __device__ __forceinline__ void fused_load_glb(const double *tab, int row, int k
   }
 }
 
-// Emission row of position gpos for this lane's KS states.  Linear form: q = product of the track rows,
-// ms = sum of their scale slots.  LOGDOM: q = exp(normalize * sum - rowmax), ms = rowmax.
-// A row no state can emit comes out as all zeros (the callers turn that into NaN).
-template <int NT, bool LOGDOM>
-__device__ __forceinline__ void fused_emission(const EmisTab &e, const FusedTab &ft, const double *lds, int64_t gpos,
-                                               int kq, int N, double (&q)[FusedGeom<NT>::KS], double &ms) {
-  using G = FusedGeom<NT>;
-  const uint32_t *row = e.obs32 + gpos * e.KPW;
-#pragma unroll
-  for (int s = 0; s < G::KS; ++s) q[s] = LOGDOM ? 0.0 : 1.0;
-  double sc = 0.0;
-  uint32_t wn = row[0];
-  for (int d = 0; d < e.KPW; ++d) {
-    const uint32_t w = wn;
-    if (d + 1 < e.KPW) wn = row[d + 1];
-#pragma unroll
-    for (int bb = 0; bb < 4; ++bb) {
-      const int k = 4 * d + bb;
-      if (k < e.K) {
-        const int sym = (int)((w >> (8 * bb)) & 0xffu);
-        const bool inr = sym < e.rowcnt[k];
-        const int lb = e.ldsbase[k];
-        double x[G::KSP];
-        if (lb >= 0) fused_load_lds<NT>(lds, inr ? lb + sym : e.lds_zero, kq, x);
-        else fused_load_glb<NT>(ft.ptab, inr ? e.rowbase[k] + sym : e.zero_row, kq, x);
-#pragma unroll
-        for (int s = 0; s < G::KS; ++s) q[s] = LOGDOM ? q[s] + x[s] : q[s] * x[s];
-        if (!LOGDOM) sc += x[G::KS];
-      }
-    }
-  }
-  if (LOGDOM) {
-    double m = -INFINITY;
-#pragma unroll
-    for (int s = 0; s < G::KS; ++s) {
-      q[s] *= e.normalize;
-      m = fmax(m, kq + 4 * s < N ? q[s] : -INFINITY);
-    }
-    m = fmax(m, __shfl_xor(m, 16));
-    m = fmax(m, __shfl_xor(m, 32));
-    const bool good = m > -1e20;
-#pragma unroll
-    for (int s = 0; s < G::KS; ++s) q[s] = (good && kq + 4 * s < N) ? exp_nonpos(q[s] - m) : 0.0;
-    ms = good ? m : 0.0;
-  } else {
-    ms = sc;
-  }
+// sum over the four lanes of an item (lanes l, l + 16, l + 32, l + 48) without going through LDS:
+// v_permlane32_swap folds the wave's halves, v_permlane16_swap the odd / even rows (see rep_rows)
+__device__ __forceinline__ double item_sum4(double t) {
+  const unsigned lo = __double2loint(t), hi = __double2hiint(t);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  const double t1 = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+  const unsigned lo1 = __double2loint(t1), hi1 = __double2hiint(t1);
+  const auto c = __builtin_amdgcn_permlane16_swap(lo1, lo1, false, false);
+  const auto d = __builtin_amdgcn_permlane16_swap(hi1, hi1, false, false);
+  return __hiloint2double((int)d[0], (int)c[0]) + __hiloint2double((int)d[1], (int)c[1]);
+}
+__device__ __forceinline__ double item_max4(double t) {
+  const unsigned lo = __double2loint(t), hi = __double2hiint(t);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  const double t1 = fmax(__hiloint2double((int)b[0], (int)a[0]), __hiloint2double((int)b[1], (int)a[1]));
+  const unsigned lo1 = __double2loint(t1), hi1 = __double2hiint(t1);
+  const auto c = __builtin_amdgcn_permlane16_swap(lo1, lo1, false, false);
+  const auto d = __builtin_amdgcn_permlane16_swap(hi1, hi1, false, false);
+  return fmax(__hiloint2double((int)d[0], (int)c[0]), __hiloint2double((int)d[1], (int)c[1]));
 }
 
-// stage the LDS-resident table rows
+// The wave's window on its index records: two 3 KB LDS buffers, the record of the next block on its way
+// through three registers per lane.  dir = +1 (forward pass: blocks ascend) or -1.
+typedef unsigned int fused_u4 __attribute__((ext_vector_type(4)));
+struct IndexWindow {
+  const fused_u4 *src;       // first record of this tile
+  unsigned lds_base;         // LDS byte address of the wave's two buffers
+  int lane, dir, NB;
+  int cur = -1;              // block currently readable in buffer (cur & 1)
+  fused_u4 r0, r1, r2;       // record of block cur + dir (valid when inflight)
+  bool inflight = false;
+
+  __device__ __forceinline__ void request(int blk) {
+    if (blk < 0 || blk >= NB) { inflight = false; return; }
+    const fused_u4 *p = src + (int64_t)blk * 192 + lane * 3;
+    r0 = p[0];
+    r1 = p[1];
+    r2 = p[2];
+    inflight = true;
+  }
+  __device__ __forceinline__ void commit(int blk) {
+    typedef __attribute__((address_space(3))) fused_u4 lds_u4;
+    lds_u4 *d = (lds_u4 *)(size_t)(lds_base + (unsigned)((blk & 1) * 3072 + lane * 48));
+    d[0] = r0;
+    d[1] = r1;
+    d[2] = r2;
+    cur = blk;
+  }
+  __device__ __forceinline__ void start(int blk) {
+    request(blk);
+    commit(blk);
+    request(blk + dir);
+  }
+  // make block `blk` readable (it is cur or cur + dir)
+  __device__ __forceinline__ void need(int blk) {
+    if (blk != cur) {
+      commit(blk);
+      request(blk + dir);
+    }
+  }
+  __device__ __forceinline__ unsigned word_addr(int blk, int r, int FKW, int w) const {
+    return lds_base + (unsigned)((blk & 1) * 3072 + ((r * FKW + w) * 16 + (lane & 15)) * 8);
+  }
+};
+__device__ __forceinline__ unsigned long long lds_read_u64(unsigned addr) {
+  typedef __attribute__((address_space(3))) const unsigned long long lds_cu64;
+  return *(lds_cu64 *)(size_t)addr;
+}
+
+// Emission row of ONE position for this lane's KS states, computed in slots that the passes interleave
+// with their matrix-core instructions (an MFMA occupies its pipe for 64 cycles during which the wave can
+// issue about a dozen independent vector instructions: two waves that run the same program in lock step
+// gain nothing from each other, so the overlap has to happen inside the wave).
+//   begin(e) ; slot(0) .. slot(NSLOT - 1) ; finish(q, ms)
+// Linear form: q = product of the track rows, ms = sum of their scale slots.  LOGDOM: q = exp(normalize *
+// sum - rowmax), ms = rowmax.  A row no state can emit comes out as all zeros (the callers turn it into NaN).
+// The schedule is FIXED at compile time (slot indices are constants of the unrolled loops; a run-time state
+// machine cost ~100 scalar instructions per slot): slot k folds the LDS track whose rows slot k - 1 requested,
+// requests the rows of LDS track k and reads the index word of track k + 1; the first global-table (L2) track
+// is requested in begin() and folded in slot GF, the second requested there and folded in finish().  Whatever
+// does not fit the slots (more than NSLOT LDS tracks, more than two global ones) is done in finish(), one
+// track after the other.
+template <int NT, bool LOGDOM>
+struct EmisStream {
+  using G = FusedGeom<NT>;
+  static constexpr int NSLOT = G::KS;
+  static constexpr int GF = NSLOT >= 8 ? 4 : NSLOT / 2;
+  const FusedTab &ft;
+  const double *lds;
+  IndexWindow &win;
+  const int kq;
+  unsigned wbase = 0;                            // LDS address of word 0 of the position being gathered
+  double q[G::KS];
+  double sc = 0.0;
+  double xa[G::KSP];                             // global-table (L2) track in flight
+  double xc[G::KSP];                             // LDS track in flight (requested in one slot, folded in the next)
+  unsigned long long wcur = 0;                   // index word of the next LDS track
+  int nl;                                        // LDS tracks handled in slots (the rest in finish)
+
+  __device__ __forceinline__ EmisStream(const FusedTab &ft_, const double *lds_, IndexWindow &win_, int kq_)
+      : ft(ft_), lds(lds_), win(win_), kq(kq_) {
+    nl = min(ft.K - ft.n_glb, NSLOT);
+  }
+  static __device__ __forceinline__ int entry(unsigned long long w, int i) { return (int)((w >> (16 * (i & 3))) & 0xffffull); }
+  __device__ __forceinline__ unsigned long long word(int w) const { return lds_read_u64(wbase + (unsigned)w * 128u); }
+  __device__ __forceinline__ void fold(const double (&x)[G::KSP]) {
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s) q[s] = LOGDOM ? q[s] + x[s] : q[s] * x[s];
+    if (!LOGDOM) sc += x[G::KS];
+  }
+  __device__ __forceinline__ void glb_request(int i) { fused_load_glb<NT>(ft.ptab, entry(word(i >> 2), i), kq, xa); }
+  // e = extended step of the position to gather (the window must hold its block)
+  __device__ __forceinline__ void begin(int e) {
+    const int blk = e / ft.SB, r = e - blk * ft.SB;
+    win.need(blk);
+    wbase = win.word_addr(blk, r, ft.FKW, 0);
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s) q[s] = LOGDOM ? 0.0 : 1.0;
+    sc = 0.0;
+    if (ft.n_glb > 0) glb_request(0);
+    if (nl > 0) wcur = word(ft.n_glb >> 2);
+  }
+  __device__ __forceinline__ void slot(int k) {
+    const int il = ft.n_glb + k;                                // this slot's LDS track
+    if (k > 0 && k <= nl) fold(xc);                             // requested by the previous slot
+    if (k == GF && NSLOT > 1) {
+      if (ft.n_glb > 0) fold(xa);
+      if (ft.n_glb > 1) glb_request(1);
+    }
+    if (k < nl) fused_load_lds<NT>(lds, entry(wcur, il), kq, xc);
+    if (k + 1 < nl) wcur = word((il + 1) >> 2);
+  }
+  __device__ __forceinline__ void finish(int N, double (&qo)[G::KS], double &ms) {
+    if (nl == NSLOT) fold(xc);                                  // the last slot's track
+    if (NSLOT > 1) {
+      if (ft.n_glb > 1) fold(xa);
+    } else if (ft.n_glb > 0) {
+      fold(xa);
+    }
+    for (int i = NSLOT > 1 ? 2 : 1; i < ft.n_glb; ++i) {        // further global tracks, one after the other
+      glb_request(i);
+      fold(xa);
+    }
+    for (int il = ft.n_glb + NSLOT; il < ft.K; ++il) {          // LDS tracks beyond the slots
+      fused_load_lds<NT>(lds, entry(word(il >> 2), il), kq, xc);
+      fold(xc);
+    }
+    if (LOGDOM) {
+      double m = -INFINITY;
+#pragma unroll
+      for (int s = 0; s < G::KS; ++s) {
+        q[s] *= ft.normalize;
+        m = fmax(m, kq + 4 * s < N ? q[s] : -INFINITY);
+      }
+      m = item_max4(m);
+      const bool good = m > -1e20;
+#pragma unroll
+      for (int s = 0; s < G::KS; ++s) qo[s] = (good && kq + 4 * s < N) ? exp_nonpos(q[s] - m) : 0.0;
+      ms = good ? m : 0.0;
+    } else {
+#pragma unroll
+      for (int s = 0; s < G::KS; ++s) qo[s] = q[s];
+      ms = sc;
+    }
+  }
+};
+
+// LDS of a fused pass: table rows [lds_rows][ROW_D_LDS] doubles | per wave two index buffers of 3 KB | (backward
+// pass) per wave a [16][NT] tile of posterior values + 16 row bases for the transposing store
 template <int NT>
-__device__ __forceinline__ void fused_stage(const EmisTab &e, const FusedTab &ft, double *lds) {
-  const int n = e.lds_rows * FusedGeom<NT>::ROW_D;
+__host__ __device__ inline size_t fused_lds_bytes(int lds_rows, bool post_tiles) {
+  return (size_t)lds_rows * FusedGeom<NT>::ROW_D_LDS * 8 + 4 * 2 * 3072 + (post_tiles ? 4 * (16 * NT * 8 + 128) : 0);
+}
+template <int NT>
+__device__ __forceinline__ void fused_stage(const FusedTab &ft, double *lds) {
+  const int n = ft.lds_rows * FusedGeom<NT>::ROW_D_LDS;
   for (int i = threadIdx.x; i < n; i += blockDim.x) lds[i] = ft.ptab_lds[i];
+}
+
+// Observation rows -> index records (see FusedTab).  order[i] = the track processed i-th.
+struct FusedOrder {
+  int K, n_glb, FKW, KP, SB, NB, Wu;
+  int zero_glb, zero_lds;
+  unsigned char order[TEHMM_MAX_TRACKS];
+  int base[TEHMM_MAX_TRACKS];        // by processing slot: row base in the table the slot reads
+  int cnt[TEHMM_MAX_TRACKS];         // by processing slot: rows of the track
+};
+// one thread per (tile, extended step, item in tile): FKW words
+__global__ __launch_bounds__(256) void k_fused_rowindex(IntervalTab iv, LaneGeom lg, FusedOrder fo, const uint8_t *obs,
+                                                        unsigned long long *rixx) {
+  const int E = fo.NB * fo.SB;
+  const int64_t n = (int64_t)lg.n_groups * 4 * E * 16;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int i16 = (int)(idx & 15);
+    const int64_t te = idx >> 4;
+    const int e = (int)(te % E);
+    const int64_t tile = te / E;
+    const int64_t item = tile * 16 + i16;
+    const bool valid = item < lg.n_items;
+    const int id = valid ? lg.item_iv[item] : 0;
+    const int64_t T = iv.len[id];
+    int64_t t = (valid ? lg.item_t0[item] : 0) - fo.Wu + e;
+    t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+    const uint8_t *orow = obs + (iv.pos0[id] + (T > 0 ? t : 0)) * fo.KP;
+    const int blk = e / fo.SB, r = e - blk * fo.SB;
+    unsigned long long *dst = rixx + ((tile * fo.NB + blk) * TEHMM_FUSED_BLKW + (int64_t)r * fo.FKW) * 16 + i16;
+    for (int w = 0; w < fo.FKW; ++w) {
+      unsigned long long word = 0;
+      for (int b = 0; b < 4; ++b) {
+        const int i = 4 * w + b;
+        int v = 0;
+        if (i < fo.K) {
+          const int sym = orow[fo.order[i]];
+          v = sym < fo.cnt[i] ? fo.base[i] + sym : (i < fo.n_glb ? fo.zero_glb : fo.zero_lds);
+        }
+        word |= (unsigned long long)(v & 0xffff) << (16 * b);
+      }
+      dst[(int64_t)w * 16] = word;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
 // Forward pass.  Same contract as k_fb_lane<NT, 0> / k_fb_mfma<NT, 0>: alpha' rows of the official range
 // (item-interleaved), pre / end vectors, cumulative log-scale records; the emission rows are computed here.
+// Extended step e <-> position t0 - Wu + e; the pass covers e = 0 .. L + Wu - 1.
 // ------------------------------------------------------------------------------------------
 template <int NT, bool LOGDOM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_fused_fwd(IntervalTab iv, EmisTab em, FusedTab ft, LaneGeom lg, int N, int CS, int Wu,
-                 const double *__restrict__ tab /* A, [NT][NT] row-major */, double *rows, double *pre,
+void k_fused_fwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu,
+                 const double *__restrict__ tab /* A, [NT][NT] row-major */, float *al32, double *chkf, double *pre,
                  double *end, double *slog32) {
   using G = FusedGeom<NT>;
   constexpr int KS = G::KS, RT = G::RT;
   extern __shared__ double fused_lds[];
-  fused_stage<NT>(em, ft, fused_lds);
+  fused_stage<NT>(ft, fused_lds);
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -145,7 +342,7 @@ void k_fused_fwd(IntervalTab iv, EmisTab em, FusedTab ft, LaneGeom lg, int N, in
   const bool valid = item < lg.n_items;
   const int id = valid ? lg.item_iv[item] : 0;
   const int64_t t0 = valid ? lg.item_t0[item] : 0;
-  const int64_t T = iv.len[id], p0 = iv.pos0[id];
+  const int64_t T = iv.len[id];
   const int64_t ct0 = (t0 / CS) * CS;
   const bool run = valid && ct0 + CS <= T && ct0 > 0;
   if (!__any(run)) return;
@@ -162,32 +359,57 @@ void k_fused_fwd(IntervalTab iv, EmisTab em, FusedTab ft, LaneGeom lg, int N, in
 #pragma unroll
   for (int s = 0; s < KS; ++s) v[s] = (kq + 4 * s < N) ? 1.0 / (double)N : 0.0;
   double slog = 0.0;
-  const int64_t soff = (int64_t)kq << 6;
-  const int64_t gbase = p0 + (run ? t0 : 0);       // lanes that do not run read some valid row
   auto vec_out = [&](double *dst) {
     const int64_t po = ((((item >> 6) * NT) + kq) << 6) + (item & 63);
 #pragma unroll
     for (int s = 0; s < KS; ++s) dst[po + ((int64_t)(4 * s) << 6)] = v[s];
   };
   const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+  IndexWindow win;
+  win.src = (const fused_u4 *)ft.rixx + (int64_t)tile * ft.NB * 192;
+  win.lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) const double *)fused_lds +
+                 (unsigned)(ft.lds_rows * G::ROW_D_LDS * 8 + (threadIdx.x >> 6) * 2 * 3072);
+  win.lane = lane;
+  win.dir = 1;
+  win.NB = ft.NB;
+  win.start(0);
   double q[KS], ms;
-  fused_emission<NT, LOGDOM>(em, ft, fused_lds, gbase + (run ? -Wu : 0), kq, N, q, ms);
+  EmisStream<NT, LOGDOM> es(ft, fused_lds, win, kq);
+  es.begin(0);
+#pragma unroll
+  for (int k = 0; k < KS; ++k) es.slot(k);
+  es.finish(N, q, ms);
+  const int E1 = ft.NB * ft.SB - 1;                  // last extended step the records hold
+  es.begin(min(1, E1));
+#ifdef TEHMM_STAMPS
+  unsigned long long stq[4] = {0, 0, 0, 0}, stt = stamp_now();
+#define FST(i) do { const unsigned long long n_ = stamp_now(); stq[i] += n_ - stt; stt = n_; } while (0)
+#else
+#define FST(i)
+#endif
   for (int s = -Wu; s < L; ++s) {
     if (s == 0) {
       if (run) vec_out(pre);
       slog = 0.0;
     }
-    // the product goes to the matrix cores first; the next position's emission row is gathered meanwhile
+    FST(3);
+    // the product on the matrix cores, the next position's emission row gathered between its instructions
     lane_d4 acc[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) acc[rt] = (lane_d4){0.0, 0.0, 0.0, 0.0};
+    // (the gather of position s + 1 was begun before the previous step's stores: vector-memory waits complete
+    //  in issue order, and the first table load must not queue up behind them)
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(tf[rt][k], v[k], acc[rt], 0, 0, 0);
+      es.slot(k);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    FST(0);
     double qn[KS], msn = 0.0;
-    if (s + 1 < L) fused_emission<NT, LOGDOM>(em, ft, fused_lds, gbase + (run ? s + 1 : 0), kq, N, qn, msn);
+    es.finish(N, qn, msn);
+    FST(1);
     double a[KS];
     double t = 0.0;
 #pragma unroll
@@ -195,41 +417,61 @@ void k_fused_fwd(IntervalTab iv, EmisTab em, FusedTab ft, LaneGeom lg, int N, in
       a[k] = acc[k >> 2][k & 3] * q[k];
       t += a[k];
     }
-    t += __shfl_xor(t, 16);
-    t += __shfl_xor(t, 32);
+    t = item_sum4(t);
     const int e = ((__double2hiint(t) >> 20) & 0x7ff) - 1022;
-    // nothing can emit here / the product underflowed: poison the item (its links fail, the exact chain walks)
+    // scale by 2^-e; nothing can emit here / the product underflowed: scale by NaN instead, which poisons the
+    // item (its links fail, the exact chain walks)
     const bool okrow = t > 1e-280 && t < INFINITY;
+    const double scale = okrow ? __hiloint2double((1023 - e) << 20, 0) : qnan;
 #pragma unroll
-    for (int k = 0; k < KS; ++k) v[k] = okrow ? ldexp(a[k], -e) : qnan;
+    for (int k = 0; k < KS; ++k) v[k] = a[k] * scale;
     slog += (double)e * 0.6931471805599453 + ms;
-    if (s >= 0 && run) {
-      const int64_t o = lane_row(lg, NT, item, s) + soff;
-#pragma unroll
-      for (int k = 0; k < KS; ++k) rows[o + ((int64_t)(4 * k) << 6)] = v[k];
-      if ((s & 31) == 31 && kq == 0) slog32[item * (L / 32) + (s >> 5)] = slog;
-    }
 #pragma unroll
     for (int k = 0; k < KS; ++k) q[k] = qn[k];
+    const double ms_now = ms;
     ms = msn;
+    (void)ms_now;
+    es.begin(min(s + 2 + Wu, E1));        // next step's gather: its first loads go out ahead of the stores below
+    FST(2);
+    if (s >= 0 && run) {
+      // alpha' row as floats: five float2 per lane (states kq + 4 (2p), kq + 4 (2p + 1)), 512 bytes per wave store
+      float2 *ar = (float2 *)al32 + al32_index(lg, item, s, kq) / 2;
+#pragma unroll
+      for (int p = 0; p < (KS + 1) / 2; ++p)
+        ar[(int64_t)p * 64] = make_float2((float)v[2 * p], 2 * p + 1 < KS ? (float)v[2 * p + 1] : 0.f);
+      if ((s & 31) == 31) {
+        if (kq == 0) slog32[item * (L / 32) + (s >> 5)] = slog;
+        if ((s & 63) == 31) {                              // fp64 row where the exact chain checks its direction
+          double *cr = chkf + (item * (L / 64) + (s >> 6)) * NT + kq;
+#pragma unroll
+          for (int k = 0; k < KS; ++k) cr[4 * k] = v[k];
+        }
+      }
+    }
   }
   if (run) vec_out(end);
+#ifdef TEHMM_STAMPS
+  if (lane == 0 && blockIdx.x < 4096)
+    for (int i = 0; i < 4; ++i) g_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + i] = stq[i];
+#endif
+#undef FST
 }
 
 // ------------------------------------------------------------------------------------------
 // Backward pass + posterior.  v = w_{t+1} = bh'_{t+1} * beta_{t+1} -> beta_t = normalise(A v); the posterior
 // row normalise(alpha'_t * beta_t) (+ eps quirk) goes straight to post [T][N]; chk [item][L / 64][NT]
 // keeps beta_t at the positions == 31 (mod 64), where k_fb_fix checks its direction.
+// Item-relative step s (L + Wu - 1 down to 0) <-> extended step s + Wu.
 // ------------------------------------------------------------------------------------------
 template <int NT, bool LOGDOM, bool EPS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_fused_bwd(IntervalTab iv, EmisTab em, FusedTab ft, LaneGeom lg, int N, int CS, int Wu,
-                 const double *__restrict__ tab /* A, [NT][NT] row-major */, const double *__restrict__ alpha,
+void k_fused_bwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu,
+                 const double *__restrict__ tab /* A, [NT][NT] row-major */, const float *__restrict__ al32,
                  double *post, double *pre, double *end, double *chk) {
   using G = FusedGeom<NT>;
   constexpr int KS = G::KS, RT = G::RT;
   extern __shared__ double fused_lds[];
-  fused_stage<NT>(em, ft, fused_lds);
+  fused_stage<NT>(ft, fused_lds);
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -240,7 +482,7 @@ void k_fused_bwd(IntervalTab iv, EmisTab em, FusedTab ft, LaneGeom lg, int N, in
   const bool valid = item < lg.n_items;
   const int id = valid ? lg.item_iv[item] : 0;
   const int64_t t0 = valid ? lg.item_t0[item] : 0;
-  const int64_t T = iv.len[id], p0 = iv.pos0[id];
+  const int64_t T = iv.len[id];
   const int64_t ct0 = (t0 / CS) * CS;
   const bool run = valid && ct0 + CS <= T && ct0 + CS < T;
   if (!__any(run)) return;
@@ -257,8 +499,6 @@ void k_fused_bwd(IntervalTab iv, EmisTab em, FusedTab ft, LaneGeom lg, int N, in
   double v[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) v[s] = 0.0;
-  const int64_t soff = (int64_t)kq << 6;
-  const int64_t gbase = p0 + (run ? t0 : 0);
   const int64_t prow0 = (iv.out0[id] + t0) * N;       // posterior row of the item's first position
   auto vec_out = [&](double *dst) {
     const int64_t po = ((((item >> 6) * NT) + kq) << 6) + (item & 63);
@@ -269,40 +509,76 @@ void k_fused_bwd(IntervalTab iv, EmisTab em, FusedTab ft, LaneGeom lg, int N, in
   const double inv_epsden = 1.0 / (1.0 + (double)N * eps);
   const double qnan = __longlong_as_double(0x7ff8000000000000LL);
   const int top = L + wu - 1;                          // first (highest) warm-up position of this item
-  auto pos_of = [&](int s) { return s >= L ? max(min(s, top), L) : s; };
+  // (the emission row is gathered at step s itself also above `top`: positions beyond the interval end
+  //  were clamped when the records were built and v is forced to zero there)
+  IndexWindow win;
+  win.src = (const fused_u4 *)ft.rixx + (int64_t)tile * ft.NB * 192;
+  win.lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) const double *)fused_lds +
+                 (unsigned)(ft.lds_rows * G::ROW_D_LDS * 8 + (threadIdx.x >> 6) * 2 * 3072);
+  win.lane = lane;
+  win.dir = -1;
+  win.NB = ft.NB;
+  win.start((L + 2 * Wu - 1) / ft.SB);
+  // Transposing store of the posterior rows.  A lane holds 9 scattered states of one item: stored directly,
+  // every store instruction is 16 pieces of 32 bytes in 16 different rows, and the wave then spends ~40 % of its
+  // time waiting for them to retire.  Instead the 16 x N values of a step go through an LDS tile and leave as 9
+  // stores of 64 consecutive doubles of the [16][NT] tile: runs of up to 280 contiguous bytes per row.
+  typedef __attribute__((address_space(3))) double lds_f64;
+  typedef __attribute__((address_space(3))) long long lds_i64;
+  const unsigned ptile = (unsigned)(size_t)(__attribute__((address_space(3))) const double *)fused_lds +
+                         (unsigned)(ft.lds_rows * G::ROW_D_LDS * 8 + 4 * 2 * 3072 + (threadIdx.x >> 6) * (16 * NT * 8 + 128));
+  const unsigned pinfo = ptile + 16 * NT * 8;
+  if (kq == 0) *(lds_i64 *)(size_t)(pinfo + (lane & 15) * 8) = run ? (long long)prow0 : -1ll;
   double q[KS], ms;
-  fused_emission<NT, LOGDOM>(em, ft, fused_lds, gbase + (run ? pos_of(L + Wu - 1) : 0), kq, N, q, ms);
+  EmisStream<NT, LOGDOM> es(ft, fused_lds, win, kq);
+  es.begin(L + 2 * Wu - 1);
+#pragma unroll
+  for (int k = 0; k < KS; ++k) es.slot(k);
+  es.finish(N, q, ms);
+  es.begin(max(L + 2 * Wu - 2, 0));
+#ifdef TEHMM_STAMPS
+  unsigned long long stq[4] = {0, 0, 0, 0}, stt = stamp_now();
+#define FST(i) do { const unsigned long long n_ = stamp_now(); stq[i] += n_ - stt; stt = n_; } while (0)
+#else
+#define FST(i)
+#endif
   for (int s = L + Wu - 1; s >= 0; --s) {
     if (s == L - 1 && run) vec_out(pre);               // v = w_{t0+L} after the warm-up
+    FST(3);
     lane_d4 acc[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) acc[rt] = (lane_d4){0.0, 0.0, 0.0, 0.0};
+    // (the gather of position s - 1 was begun before the previous step's stores, see k_fused_fwd)
+    // alpha' row of this position (official range only; floats, five float2 per lane)
+    float2 alp[(KS + 1) / 2];
+    if (s < L) {
+      const float2 *ar = (const float2 *)al32 + al32_index(lg, item, s, kq) / 2;
+#pragma unroll
+      for (int p = 0; p < (KS + 1) / 2; ++p) alp[p] = run ? ar[(int64_t)p * 64] : make_float2(0.f, 0.f);
+    }
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(tf[rt][k], v[k], acc[rt], 0, 0, 0);
+      es.slot(k);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    FST(0);
     double qn[KS], msn = 0.0;
-    if (s > 0) fused_emission<NT, LOGDOM>(em, ft, fused_lds, gbase + (run ? pos_of(s - 1) : 0), kq, N, qn, msn);
-    // alpha' row of this position (official range only), requested before the reduction that needs it
-    double al[KS];
-    const int64_t o = lane_row(lg, NT, item, s < L ? s : 0) + soff;
-    if (s < L) {
-#pragma unroll
-      for (int k = 0; k < KS; ++k) al[k] = run ? alpha[o + ((int64_t)(4 * k) << 6)] : 0.0;
-    }
+    es.finish(N, qn, msn);
+    FST(1);
     double t = 0.0;
 #pragma unroll
     for (int k = 0; k < KS; ++k) t += acc[k >> 2][k & 3];
-    t += __shfl_xor(t, 16);
-    t += __shfl_xor(t, 32);
+    t = item_sum4(t);
     const int e = ((__double2hiint(t) >> 20) & 0x7ff) - 1022;
     double bt[KS];
     // an impossible emission row (all zeros) must poison the item: q enters v below, a zero v gives t = 0
     const bool okrow = (s >= L && s >= top) || (t > 0.0 && t < INFINITY);
+    const double scale = okrow ? __hiloint2double((1023 - e) << 20, 0) : qnan;
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
-      bt[k] = okrow ? ldexp(acc[k >> 2][k & 3], -e) : qnan;                // beta_t
+      bt[k] = acc[k >> 2][k & 3] * scale;                                  // beta_t
       if (s >= L && s == top) bt[k] = kq + 4 * k < N ? 1.0 : 0.0;           // uniform start
     }
     if (s < L) {
@@ -310,20 +586,36 @@ void k_fused_bwd(IntervalTab iv, EmisTab em, FusedTab ft, LaneGeom lg, int N, in
       double g[KS], gt = 0.0;
 #pragma unroll
       for (int k = 0; k < KS; ++k) {
-        g[k] = al[k] * bt[k];
+        g[k] = (double)((k & 1) ? alp[k >> 1].y : alp[k >> 1].x) * bt[k];
         gt += g[k];
       }
-      gt += __shfl_xor(gt, 16);
-      gt += __shfl_xor(gt, 32);
+      gt = item_sum4(gt);
       const double inv = 1.0 / gt;
-      if (run) {
-        double *pr = post + prow0 + (int64_t)s * N + kq;
 #pragma unroll
-        for (int k = 0; k < KS; ++k) {
-          double p = g[k] * inv;
-          if (EPS) p = (p + eps) * inv_epsden;
-          if (kq + 4 * k < N) pr[4 * k] = p;
+      for (int k = 0; k < KS; ++k) {
+        g[k] *= inv;
+        if (EPS) g[k] = (g[k] + eps) * inv_epsden;
+      }
+#pragma unroll
+      for (int k = 0; k < KS; ++k) v[k] = q[k] * bt[k];
+#pragma unroll
+      for (int k = 0; k < KS; ++k) q[k] = qn[k];
+      es.begin(max(s - 2 + Wu, 0));       // next step's gather: its first loads go out ahead of the stores below
+#pragma unroll
+      for (int k = 0; k < KS; ++k) *(lds_f64 *)(size_t)(ptile + (unsigned)(((lane & 15) * NT + kq + 4 * k) * 8)) = g[k];
+      int lane_v = lane;                                   // (opaque: keeps the per-store index arithmetic inside
+      asm volatile("" : "+v"(lane_v));                     //  the step instead of 27 hoisted registers)
+#pragma unroll
+      for (int j = 0; j < (16 * NT + 63) / 64; ++j) {
+        const int e = 64 * j + lane_v;                     // element of the [16][NT] tile, row-major
+        if (16 * NT % 64 == 0 || e < 16 * NT) {
+          const int r = (e * (65536 / NT + 1)) >> 16, c = e - r * NT;        // e / NT, e % NT (e < 16 NT <= 1024)
+          const double val = *(lds_f64 *)(size_t)(ptile + (unsigned)e * 8u);
+          const long long base = *(lds_i64 *)(size_t)(pinfo + (unsigned)r * 8u);
+          if (base >= 0 && c < N) post[base + (int64_t)s * N + c] = val;
         }
+      }
+      if (run) {
         if ((s & 63) == 31) {
           double *cr = chk + (item * (L / 64) + (s >> 6)) * NT + kq;
 #pragma unroll
@@ -331,14 +623,23 @@ void k_fused_bwd(IntervalTab iv, EmisTab em, FusedTab ft, LaneGeom lg, int N, in
         }
       }
     }
+    if (s >= L) {                          // warm-up steps: no posterior, nothing stored
 #pragma unroll
-    for (int k = 0; k < KS; ++k) v[k] = (s >= L && s > top) ? 0.0 : q[k] * bt[k];
+      for (int k = 0; k < KS; ++k) v[k] = s > top ? 0.0 : q[k] * bt[k];
 #pragma unroll
-    for (int k = 0; k < KS; ++k) q[k] = qn[k];
+      for (int k = 0; k < KS; ++k) q[k] = qn[k];
+      es.begin(max(s - 2 + Wu, 0));
+    }
+    FST(2);
     ms = msn;
   }
   (void)ms;
   if (run) vec_out(end);
+#ifdef TEHMM_STAMPS
+  if (lane == 0 && blockIdx.x < 4096)
+    for (int i = 0; i < 4; ++i) g_stamps[4096 * 16 + (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + i] = stq[i];
+#endif
+#undef FST
 }
 
 }  // namespace tehmm

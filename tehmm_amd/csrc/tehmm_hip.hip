@@ -8,6 +8,7 @@
 #include "tehmm_fused.hip.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -115,6 +116,7 @@ struct tehmm_model {
   DBuf<double> ptab, ptab_lds;
   DBuf<int> d_rowinfo;         // rowbase[K] | rowcnt[K] | ldsbase[K] on the device
   int KSP = 0;
+  uint64_t uid = 0;            // unique per model handle (workspaces derived from the table layout are keyed on it)
   bool ptab_log = false;       // log-domain rows (normalizeFac != 1): the product form does not apply
   int rowbase[TEHMM_MAX_TRACKS];
   int rowcnt[TEHMM_MAX_TRACKS];
@@ -156,7 +158,11 @@ struct LaneWork {
   DBuf<double> glog_f, cpre_f, dl_f, lr_f, dl_b;
   DBuf<int64_t> item_t0, ifirst;
   DBuf<double> B, BH, MS, AL, BE, pre_f, end_f, pre_b, end_b, slog32;
-  DBuf<double> chk;           // fused passes: speculative beta rows at the chain's check positions
+  DBuf<double> chk, chkf;     // fused passes: speculative beta / alpha' rows at the chains' check positions
+  DBuf<float> AL32;           // fused passes: alpha' rows as floats (al32_index)
+  DBuf<unsigned long long> rix;   // fused passes: observation rows as table-row index records (FusedTab::rixx)
+  uint64_t rix_model = 0;
+  int rix_L = 0, rix_Wu = 0;
   // Viterbi lane passes
   DBuf<double> vpre, vend, vgain, vtierows, vpiecemin, qtabs;
   DBuf<float> B32;
@@ -401,12 +407,12 @@ int tehmm_update_counts_i32(int64_t T, int K, int N, int S, const int32_t *obs, 
 // (Re)build the fused passes' emission tables from m->tab (model creation, M-step).
 static int build_ptab(tehmm_model *m) {
   if (m->NP > 36) return TEHMM_OK;              // the lane passes are instantiated up to 36 padded states
-  const int KS = m->NP / 4, KSP = ((KS + 1) + 1) & ~1, ROW_D = 4 * KSP, K = m->K;
+  const int KS = m->NP / 4, KSP = ((KS + 1) + 1) & ~1, ROW_D = 4 * KSP, ROW_L = ROW_D + 2, K = m->K;
   m->KSP = KSP;
   m->ptab_log = m->normalize != 1.0;
   if (!m->ptab.p) {
     HIPCHK(m->ptab.alloc((size_t)(m->R + 1) * ROW_D));
-    HIPCHK(m->ptab_lds.alloc((size_t)std::max(1, m->lds_rows) * ROW_D));
+    HIPCHK(m->ptab_lds.alloc((size_t)std::max(1, m->lds_rows) * ROW_L));
     std::vector<int> info((size_t)3 * K);
     for (int k = 0; k < K; ++k) { info[k] = m->rowbase[k]; info[K + k] = m->rowcnt[k]; info[2 * K + k] = m->ldsbase[k]; }
     HIPCHK(m->d_rowinfo.upload(info.data(), info.size()));
@@ -416,7 +422,7 @@ static int build_ptab(tehmm_model *m) {
   if (m->lds_rows > 0)
     hipLaunchKernelGGL(k_pack_ptab_lds, dim3(K + 1), dim3(256), 0, 0, K, (const int *)m->d_rowinfo.p,
                        (const int *)m->d_rowinfo.p + K, (const int *)m->d_rowinfo.p + 2 * K, m->lds_zero, m->R, ROW_D,
-                       (const double *)m->ptab.p, m->ptab_lds.p);
+                       ROW_L, (const double *)m->ptab.p, m->ptab_lds.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipDeviceSynchronize());
   return TEHMM_OK;
@@ -432,6 +438,10 @@ int tehmm_model_create(int N, int K, int S, const double *lt, const double *pi,
   if (N > kMaxStates || K > TEHMM_MAX_TRACKS || S > 256)
     return fail(TEHMM_ERR_UNSUPPORTED, "tehmm_model_create: N > 128, K > 128 or S > 256");
   tehmm_model *m = new tehmm_model();
+  {
+    static std::atomic<uint64_t> next_uid{1};
+    m->uid = next_uid.fetch_add(1);
+  }
   m->N = N;
   m->K = K;
   m->S = S;
@@ -914,7 +924,7 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
     }
     h_first[b->n] = (int64_t)h_iv.size();
     for (DBuf<double> *d : {&lw.B, &lw.BH, &lw.MS, &lw.AL, &lw.BE, &lw.pre_f, &lw.end_f, &lw.pre_b, &lw.end_b,
-                            &lw.slog32, &lw.vpre, &lw.vend, &lw.vgain, &lw.vtierows, &lw.vpiecemin, &lw.chk})
+                            &lw.slog32, &lw.vpre, &lw.vend, &lw.vgain, &lw.vtierows, &lw.vpiecemin, &lw.chk, &lw.chkf})
       d->release();
     for (DBuf<int> *d : {&lw.ok_f, &lw.ok_b, &lw.vbad, &lw.vntie, &lw.vties, &lw.link_f, &lw.link_b, &lw.runend_f,
                          &lw.runstart_b})
@@ -925,6 +935,7 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
     lw.lr_f.release();
     lw.dl_b.release();
     lw.B32.release();
+    lw.AL32.release();
     lw.L = L; lw.CS = CS; lw.NP = m->NP;
     lw.n_items = (int)h_iv.size();
     lw.n_groups = (lw.n_items + 63) / 64;
@@ -937,8 +948,9 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
   }
   const size_t rows = (size_t)std::max(1, lw.n_groups) * L * 64;        // item-interleaved positions
   const size_t vecs = (size_t)std::max(1, lw.n_groups) * 64 * m->NP;
-  if (want_fb && !lw.AL.p) {
-    HIPCHK(lw.AL.alloc(rows * m->NP));
+  if (want_fb && !lw.pre_f.p) {
+    if (fused_fb) HIPCHK(lw.AL32.alloc((size_t)std::max(1, lw.n_groups) * L * 2560));
+    else HIPCHK(lw.AL.alloc(rows * m->NP));
     HIPCHK(lw.pre_f.alloc(vecs));
     HIPCHK(lw.end_f.alloc(vecs));
     HIPCHK(lw.pre_b.alloc(vecs));
@@ -954,8 +966,12 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
     HIPCHK(lw.lr_f.alloc((size_t)std::max(1, lw.n_groups) * 64));
     HIPCHK(lw.dl_b.alloc((size_t)std::max(1, lw.n_groups) * 64));
   }
-  if (want_fb && fused_fb && !lw.chk.p)
+  if (want_fb && fused_fb && !lw.chk.p) {
     HIPCHK(lw.chk.alloc((size_t)std::max(1, lw.n_groups) * 64 * (size_t)(L / 64) * m->NP));
+    HIPCHK(lw.chkf.alloc((size_t)std::max(1, lw.n_groups) * 64 * (size_t)(L / 64) * m->NP));
+  }
+  if (want_fb && fused_fb && !lw.AL32.p) HIPCHK(lw.AL32.alloc((size_t)std::max(1, lw.n_groups) * L * 2560));
+  if (want_fb && !fused_fb && !lw.AL.p) HIPCHK(lw.AL.alloc(rows * m->NP));
   if (want_fb && !fused_fb && !lw.BH.p) {
     HIPCHK(lw.BE.alloc(rows * m->NP));
     HIPCHK(lw.BH.alloc(rows * m->NP));
@@ -1148,33 +1164,77 @@ static void launch_fused_fb(tehmm_batch *b, const tehmm_model *m, const Interval
   const dim3 gridi(std::max(1, b->n));
   const char *er = std::getenv("TEHMM_FB_RUNS");
   const int extend = (er && std::atoi(er) == 0) ? 0 : 1;
+  // processing order of the tracks: those served from the global table (L2) first, then the LDS-staged ones
+  FusedOrder fo;
+  std::memset(&fo, 0, sizeof(fo));
+  fo.K = m->K;
+  fo.KP = b->KP;
+  fo.Wu = Wu;
+  {
+    static const int ok[] = {1, 2, 3, 4, 6, 8, 12, 24};          // divisors of TEHMM_FUSED_BLKW
+    int need = (m->K + 3) / 4;
+    fo.FKW = 24;
+    for (int d : ok) if (d >= need) { fo.FKW = d; break; }
+  }
+  fo.SB = TEHMM_FUSED_BLKW / fo.FKW;
+  fo.NB = (lw.L + 2 * Wu + fo.SB - 1) / fo.SB;
+  fo.zero_glb = m->R;
+  fo.zero_lds = m->lds_zero;
+  int slot = 0;
+  for (int pass = 0; pass < 2; ++pass)
+    for (int k = 0; k < m->K; ++k) {
+      const bool in_lds = m->ldsbase[k] >= 0;
+      if ((pass == 0) == in_lds) continue;
+      fo.order[slot] = (unsigned char)k;
+      fo.base[slot] = in_lds ? m->ldsbase[k] : m->rowbase[k];
+      fo.cnt[slot] = m->rowcnt[k];
+      ++slot;
+      if (pass == 0) fo.n_glb = slot;
+    }
+  if (!lw.rix.p || lw.rix_model != m->uid || lw.rix_L != lw.L || lw.rix_Wu != Wu) {
+    const size_t words = (size_t)lw.n_groups * 4 * fo.NB * TEHMM_FUSED_BLKW * 16;
+    (void)lw.rix.ensure(words + 16);
+    hipLaunchKernelGGL(k_fused_rowindex, dim3(grid_for((int64_t)lw.n_groups * 4 * fo.NB * fo.SB * 16, 256, 1 << 20)),
+                       dim3(256), 0, st, iv, lg, fo, (const uint8_t *)b->obs.p, lw.rix.p);
+    lw.rix_model = m->uid;
+    lw.rix_L = lw.L;
+    lw.rix_Wu = Wu;
+  }
   FusedTab ft;
+  ft.rixx = lw.rix.p;
   ft.ptab = m->ptab.p;
   ft.ptab_lds = m->ptab_lds.p;
+  ft.FKW = fo.FKW;
+  ft.SB = fo.SB;
+  ft.NB = fo.NB;
+  ft.K = m->K;
+  ft.n_glb = fo.n_glb;
+  ft.lds_rows = m->lds_rows;
+  ft.normalize = m->normalize;
   const EmisTab emc = b->n > 256 ? without_lds_tables(em_in) : em_in;          // the chains' own emission rows
-  const size_t lds_f = (size_t)em_in.lds_rows * FusedGeom<NT>::ROW_D * sizeof(double);
+  const size_t lds_f = fused_lds_bytes<NT>(m->lds_rows, false), lds_b = fused_lds_bytes<NT>(m->lds_rows, true);
   const size_t lds_c = ((size_t)2 * 64 * (NT + 1) + 2 * 64 + NT + (size_t)emc.lds_rows * NT + 8) * sizeof(double);
-  allow_lds(k_fb_fix<NT, 0, false, true>, lds_c);
+  allow_lds(k_fb_fix<NT, 0, false, true, true>, lds_c);
   allow_lds(k_fb_fix<NT, 1, false, true, true>, lds_c);
 #define TEHMM_FUSED_LAUNCH(LOG_)                                                                                     \
   do {                                                                                                              \
     allow_lds(k_fused_fwd<NT, LOG_>, lds_f);                                                                         \
-    allow_lds(k_fused_bwd<NT, LOG_, true>, lds_f);                                                                   \
-    hipLaunchKernelGGL((k_fused_fwd<NT, LOG_>), gridm, dim3(256), lds_f, st, iv, em_in, ft, lg, m->N, fc.CS, Wu,     \
-                       (const double *)m->A.p, lw.AL.p, lw.pre_f.p, lw.end_f.p, lw.slog32.p);                        \
+    allow_lds(k_fused_bwd<NT, LOG_, true>, lds_b);                                                                   \
+    hipLaunchKernelGGL((k_fused_fwd<NT, LOG_>), gridm, dim3(256), lds_f, st, iv, ft, lg, m->N, fc.CS, Wu,            \
+                       (const double *)m->A.p, lw.AL32.p, lw.chkf.p, lw.pre_f.p, lw.end_f.p, lw.slog32.p);           \
     hipLaunchKernelGGL((k_fb_itemlinks<NT>), gridit, dim3(256), 0, st, lg, m->N, lw.pre_f.p, lw.end_f.p,             \
                        lw.pre_b.p, lw.end_b.p, lw.dl_f.p, lw.lr_f.p, lw.dl_b.p, 1);                                  \
     hipLaunchKernelGGL((k_fb_stitch<NT>), gridc, dim3(256), 0, st, iv, lg, fc, m->N, lw.slog32.p, lw.end_b.p,        \
                        lw.dl_f.p, lw.lr_f.p, lw.dl_b.p, lw.ok_f.p, lw.ok_b.p, 1);                                    \
     hipLaunchKernelGGL(k_fb_runs, gridi, dim3(64), 0, st, iv, fc, (const int *)lw.ok_f.p, (const int *)lw.ok_b.p,    \
                        extend, 1);                                                                                   \
-    hipLaunchKernelGGL((k_fb_fix<NT, 0, false, true>), dim3(b->n), dim3(128), lds_c, st, iv, emc, fc, m->N, m->A.p,   \
-                       m->lt.p, m->pi.p, (const double *)nullptr, lw.AL.p, b->fwd_lp.p, b->dead.p,                   \
+    hipLaunchKernelGGL((k_fb_fix<NT, 0, false, true, true>), dim3(b->n), dim3(128), lds_c, st, iv, emc, fc, m->N,    \
+                       m->A.p, m->lt.p, m->pi.p, (const double *)nullptr, (double *)nullptr, b->fwd_lp.p, b->dead.p, \
                        (double *)nullptr, (int *)nullptr, 1, b->sw.stats.p, lg, (const int *)lw.ok_f.p,              \
-                       (const double *)nullptr, (double *)nullptr);                                                  \
+                       (const double *)lw.chkf.p, (double *)nullptr, lw.AL32.p, (const double *)lw.end_f.p);         \
     (void)hipEventRecord(ev_fwd, st);                                                                                \
-    hipLaunchKernelGGL((k_fused_bwd<NT, LOG_, true>), gridm, dim3(256), lds_f, st, iv, em_in, ft, lg, m->N, fc.CS,    \
-                       Wu, (const double *)m->A.p, (const double *)lw.AL.p, b->post.p, lw.pre_b.p, lw.end_b.p,       \
+    hipLaunchKernelGGL((k_fused_bwd<NT, LOG_, true>), gridm, dim3(256), lds_b, st, iv, ft, lg, m->N, fc.CS,           \
+                       Wu, (const double *)m->A.p, (const float *)lw.AL32.p, b->post.p, lw.pre_b.p, lw.end_b.p,      \
                        lw.chk.p);                                                                                    \
   } while (0)
   if (m->ptab_log) TEHMM_FUSED_LAUNCH(true);
@@ -1188,9 +1248,9 @@ static void launch_fused_fb(tehmm_batch *b, const tehmm_model *m, const Interval
                      extend, 2);
   (void)hipEventRecord(ev_mid, st);
   hipLaunchKernelGGL((k_fb_fix<NT, 1, false, true, true>), dim3(b->n), dim3(128), lds_c, st, iv, emc, fc, m->N, m->A.p,
-                     m->lt.p, m->pi.p, (const double *)nullptr, lw.AL.p, b->fwd_lp.p, b->dead.p,
+                     m->lt.p, m->pi.p, (const double *)nullptr, (double *)nullptr, b->fwd_lp.p, b->dead.p,
                      (double *)nullptr, (int *)nullptr, 1, b->sw.stats.p, lg, (const int *)lw.ok_b.p,
-                     (const double *)lw.chk.p, b->post.p);
+                     (const double *)lw.chk.p, b->post.p, lw.AL32.p, (const double *)nullptr);
 }
 
 template <int NT>
@@ -1286,7 +1346,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   // separate combine); default: the fused passes of tehmm_fused.hip.h
   const char *fus = std::getenv("TEHMM_FUSED");
   const bool fused_fb = !(fus && std::atoi(fus) == 0) && m->ptab.p != nullptr;
-  if (LS > 0 && !b->lw.AL.p && !b->lw.B.p && !b->lw.B32.p) {
+  if (LS > 0 && !b->lw.AL.p && !b->lw.AL32.p && !b->lw.B.p && !b->lw.B32.p) {
     // the item-interleaved buffers (8 * NP bytes per position each: alpha' -- plus, without the fused
     // passes, beta' and the linear emission rows --, the fp64 log rows of the exact Viterbi pass; 4 * NP
     // for the float rows of P0) must fit next to the results; otherwise do without the fp64 log rows, and
@@ -1294,11 +1354,11 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     const double per = (double)b->total * m->NP * 8.0;
-    const double fb_units = fspec ? (fused_fb ? 1.1 : 3.2) : 0.0, p0_units = vspec ? 0.5 : 0.0;
+    const double fb_units = fspec ? (fused_fb ? 0.7 : 3.2) : 0.0, p0_units = vspec ? 0.5 : 0.0;
     b->lw.no_vlane = per * (fb_units + p0_units + 1.0) > 0.85 * (double)free_b;
     if (per * (fb_units + p0_units) > 0.85 * (double)free_b) LS = 0;
   }
-  if (LS > 0 && want_vlane && !b->lw.no_vlane && !b->lw.B.p && (b->lw.AL.p || b->lw.B32.p)) {
+  if (LS > 0 && want_vlane && !b->lw.no_vlane && !b->lw.B.p && (b->lw.AL.p || b->lw.AL32.p || b->lw.B32.p)) {
     // workspaces of an earlier call exist already: the fp64 (+ float) log rows must still fit
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
@@ -2122,7 +2182,7 @@ int tehmm_estep_batch(tehmm_model_t *m, tehmm_batch_t *b, int use_ratios, double
 // Diagnostic: cycle stamps of the last cooperative kernel (only in the -DTEHMM_STAMPS build).
 int tehmm_debug_read_stamps(unsigned long long *out, int n) {
 #ifdef TEHMM_STAMPS
-  if (!out || n <= 0 || n > 4096 * 16) return fail(TEHMM_ERR_ARG, "tehmm_debug_read_stamps: bad argument");
+  if (!out || n <= 0 || n > 2 * 4096 * 16) return fail(TEHMM_ERR_ARG, "tehmm_debug_read_stamps: bad argument");
   HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), (size_t)n * sizeof(unsigned long long)));
   return TEHMM_OK;
 #else

@@ -29,7 +29,7 @@ namespace tehmm {
 
 // ---- diagnostic cycle stamps (only in the -DTEHMM_STAMPS build; never in the product library)
 #ifdef TEHMM_STAMPS
-__device__ unsigned long long g_stamps[4096 * 16];
+__device__ unsigned long long g_stamps[2 * 4096 * 16];
 __device__ __forceinline__ unsigned long long stamp_now() {
   unsigned long long t;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");

@@ -508,6 +508,16 @@ __device__ __forceinline__ int64_t lane_row(const LaneGeom &lg, int NT, int64_t 
   return ((((item >> 6) * lg.L + trel) * NT) << 6) + (item & 63);
 }
 
+// Fused passes (tehmm_fused.hip.h): the alpha' rows are kept in FLOAT (a posterior only needs their direction
+// to 1e-6) in a layout where the nine states of a matrix-core lane sit in five float2:
+//   element (item, t, state)  ->  [group][t][tile in group][state pair p = (state >> 2) >> 1][state & 3][item & 15][(state >> 2) & 1]
+// i.e. one 512-byte row per wave load / store; 2560 floats per (group, position).
+__device__ __forceinline__ int64_t al32_index(const LaneGeom &lg, int64_t item, int64_t trel, int state) {
+  const int64_t gt = (item >> 6) * lg.L + trel;
+  const int tg = (int)((item >> 4) & 3), s = state >> 2;
+  return ((((gt * 4 + tg) * 5 + (s >> 1)) * 4 + (state & 3)) * 16 + (item & 15)) * 2 + (s & 1);
+}
+
 // Hilbert projective distance (as max/min ratio - 1) between two non-negative vectors over the live
 // lanes; returns a huge value when their supports differ or anything is not finite.  rho = the ratio
 // a / b at the lane where it is largest.
@@ -613,15 +623,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // ------------------------------------------------------------------------------------------
 // LANE: `rows` is item-interleaved (tehmm_lane.hip.h) and okc[c] tells whether the chunk's item links
 // hold; otherwise rows is [T][N] as written by k_fb_spec.
-// FUSED (backward, with the fused lane passes of tehmm_fused.hip.h): `rows` holds the alpha' rows
-// (read only); the speculative beta rows exist only at the check positions (chk [item][L / 64][NT]) and the
-// chain writes the posterior rows normalise(alpha' * beta) of its exact blocks (+ eps quirk) to post.
+// FUSED (with the fused lane passes of tehmm_fused.hip.h): the alpha' rows live in al32 (float, al32_index);
+// speculative rows in fp64 exist only at the check positions (chk [item][L / 64][NT]) and at the item ends
+// (endv, the lane pass's end vectors).  Forward: exact rows are written to al32, a jump adopts endv.
+// Backward: al32 is read only and the chain writes the posterior rows normalise(alpha' * beta) of its exact
+// blocks (+ eps quirk) to post.
 template <int NT, int DIR, bool TRATIO, bool LANE, bool FUSED = false>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A, const double *g_lt,
               const double *g_pi, const double *tratios, double *rows, double *fwd_logprob,
               int *dead_flag, double *wrows, int *escale, int allow_jump, int *stats, LaneGeom lg,
-              const int *okc, const double *chk = nullptr, double *post = nullptr) {
+              const int *okc, const double *chk = nullptr, double *post = nullptr, float *al32 = nullptr,
+              const double *endv = nullptr) {
   extern __shared__ double sm[];
   constexpr int RS = NT + 1;
   constexpr int CPB = 64;
@@ -720,7 +733,7 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
       const int64_t target = DIR == 0 ? fc.t0[cj] + fc.CS : fc.t0[cj];      // key of the block after a jump
       double srow = 0.0;
       if (spec) {                                               // speculative row, before overwriting
-        if (FUSED && DIR == 1)
+        if (FUSED)
           srow = live ? chk[((ifirst + tg / lg.L) * (lg.L / 64) + (tg % lg.L) / 64) * NT + jl] : 0.0;
         else
           srow = live ? brow[(tg - lo) * rstride] : 0.0;
@@ -751,7 +764,11 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
             Ecum += (double)e;
             if (es && lane == 0) es[t] = e;
           }
-          if (live) brow[p * rstride] = v;
+          if (FUSED) {
+            if (live) al32[al32_index(lg, ifirst + t / lg.L, t % lg.L, jl)] = (float)v;
+          } else if (live) {
+            brow[p * rstride] = v;
+          }
         } else {
           double bt;
           if (t == T - 1) {
@@ -792,7 +809,8 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
         const double inv_epsden = 1.0 / (1.0 + (double)N * eps);
         double *po = post + (iv.out0[id] + lo) * N;
         for (int p = 0; p < np; ++p) {
-          const double a = live ? brow[p * rstride] : 0.0;
+          const int64_t tp = lo + p;
+          const double a = live ? (double)al32[al32_index(lg, ifirst + tp / lg.L, tp % lg.L, jl)] : 0.0;
           const double g = a * (live ? br[p * RS + lane] : 0.0);
           const double tot = wave_sum_f64(g);
           if (live) po[(int64_t)p * N + lane] = (g / tot + eps) * inv_epsden;
@@ -803,7 +821,12 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
         if (DIR == 0) {
           // adopt the speculative row at the chunk end; carry the log-likelihood over the jump
           const int64_t tl = target - 1;
-          v = live ? *rowp(tl) : 0.0;
+          if (FUSED) {
+            const int64_t it_end = ifirst + tl / lg.L;              // tl is the last position of its item
+            v = live ? endv[((((it_end >> 6) * NT) + jl) << 6) + (it_end & 63)] : 0.0;
+          } else {
+            v = live ? *rowp(tl) : 0.0;
+          }
           const double *sc = fc.scale + c * (fc.CS / 32);
           Mcum = Sg + log(rho) + (sc[fc.CS / 32 - 1] - sc[(tg - ct0) / 32]);
           if (LANE) Mcum += fc.pre_f[cj] - fc.pre_f[c];

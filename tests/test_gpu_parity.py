@@ -162,7 +162,8 @@ def test_fused_batch_ragged(hip, N, with_ratio):
     t = hb.timing()
     names = {k for k in t if not k.startswith("count:")}
     assert {"viterbi", "traceback"} <= names
-    assert ({"forward", "backward_posterior"} <= names) or ({"forward_backward", "posterior_combine"} <= names)
+    assert ({"forward", "backward_posterior"} <= names) or ({"forward_backward", "posterior_combine"} <= names) \
+        or ({"forward_pass", "backward_posterior_pass", "backward_chain"} <= names)
     assert all(v >= 0.0 for v in t.values())
 
 

@@ -21,8 +21,11 @@ hb = HipBatch(obs.data_ptr(), offs, device_ptrs=True, K=model.n_tracks)
 del obs
 torch.cuda.empty_cache()
 import time
+only = os.environ.get("STAGES")          # e.g. STAGES=posterior
 for name, kw in (("posterior", dict(viterbi=False, posterior=True)), ("viterbi", dict(viterbi=True, posterior=False)),
                  ("both", dict(viterbi=True, posterior=True))):
+    if only and name not in only.split(","):
+        continue
     hm.eval(hb, **kw)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -30,3 +33,5 @@ for name, kw in (("posterior", dict(viterbi=False, posterior=True)), ("viterbi",
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) * 1e3
     print(name, "%.1f ms" % dt, json.dumps({k: round(v, 2) for k, v in hb.timing().items()}), flush=True)
+hb.close()
+hm.close()
