@@ -910,7 +910,7 @@ static int lane_sub_size(int CS, int64_t total) {
 }
 
 static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, bool want_fb, bool want_vit,
-                        bool want_gain, bool fused_fb) {
+                        bool want_gain, bool fused_fb, bool want_b32) {
   LaneWork &lw = b->lw;
   if (lw.L != L || lw.CS != CS || lw.NP != m->NP || !lw.item_iv.p) {
     std::vector<int> h_iv;
@@ -977,10 +977,10 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
     HIPCHK(lw.BH.alloc(rows * m->NP));
     if (!lw.MS.p) HIPCHK(lw.MS.alloc(rows));
   }
-  if (want_gain && !lw.B32.p) {
+  if (want_gain && !lw.vgain.p) HIPCHK(lw.vgain.alloc((size_t)std::max(1, lw.n_groups) * 64));
+  if (want_gain && want_b32 && !lw.B32.p) {
     HIPCHK(lw.B32.alloc(rows * m->NP));
     if (!lw.MS.p) HIPCHK(lw.MS.alloc(rows));
-    if (!lw.vgain.p) HIPCHK(lw.vgain.alloc((size_t)std::max(1, lw.n_groups) * 64));
   }
   if (want_vit && !lw.B.p) {
     const size_t ni = (size_t)std::max(1, lw.n_groups) * 64;
@@ -1078,6 +1078,17 @@ static void launch_emis_lane(tehmm_batch *b, const tehmm_model *m, const Interva
   hipLaunchKernelGGL((k_emis_lane<NT>), dim3((lw.n_groups + 3) / 4), dim3(256), lds, st, iv, em, lane_geom(lw),
                      m->N, want_log ? lw.B.p : (double *)nullptr, want_lin ? lw.BH.p : (double *)nullptr, lw.MS.p,
                      want_f32 ? lw.B32.p : (float *)nullptr);
+}
+
+// emission rows (fp64 log rows for the exact Viterbi pass) and P0 in one pass
+template <int NT>
+static void launch_emis_gain_lane(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em,
+                                  int CS, int Wu, hipStream_t st) {
+  LaneWork &lw = b->lw;
+  const size_t lds = (size_t)em.lds_rows * NT * sizeof(double);
+  allow_lds(k_emis_gain_lane<NT>, lds);
+  hipLaunchKernelGGL((k_emis_gain_lane<NT>), dim3((lw.n_groups + 3) / 4), dim3(256), lds, st, iv, em, lane_geom(lw),
+                     m->N, CS, Wu, (const float *)m->ltP.p, lw.B.p, lw.vgain.p);
 }
 
 template <int NT>
@@ -1354,7 +1365,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     const double per = (double)b->total * m->NP * 8.0;
-    const double fb_units = fspec ? (fused_fb ? 0.7 : 3.2) : 0.0, p0_units = vspec ? 0.5 : 0.0;
+    const double fb_units = fspec ? (fused_fb ? 0.7 : 3.2) : 0.0, p0_units = (vspec && !fused_fb) ? 0.5 : 0.0;
     b->lw.no_vlane = per * (fb_units + p0_units + 1.0) > 0.85 * (double)free_b;
     if (per * (fb_units + p0_units) > 0.85 * (double)free_b) LS = 0;
   }
@@ -1377,8 +1388,11 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   VitChunks vc;
   std::vector<double> &gain = lw.hs_gain;
   if (vit) (void)hipEventRecord(b->ev[eV], b->sV);
+  // emission rows and P0 in one pass (no float copy of the rows) unless the round-1 posterior pipeline, which
+  // takes its linear rows from the row kernel, is selected
+  const bool emis_gain = glane && !(flane && !fused_fb);
   if (vlane || flane || glane) {
-    rc = lane_prepare(b, m, CS, LS, flane, vlane, glane, fused_fb);
+    rc = lane_prepare(b, m, CS, LS, flane, vlane, glane, fused_fb, !emis_gain);
     if (rc) return rc;
   }
   // Scheduling.  The speculative Viterbi passes, the emission rows, the forward / backward lane passes
@@ -1393,9 +1407,15 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   if (vlane || glane) {
     // emission rows of every position, once, item-interleaved (log rows for Viterbi, linear for fwd/bwd)
     hipStream_t st = b->sV;
-#define CALL(NT_) launch_emis_lane<NT_>(b, m, iv, em, vlane, flane && !fused_fb, glane, st)
-    TEHMM_NT_DISPATCH(m->NP, CALL)
+    if (emis_gain) {
+#define CALL(NT_) launch_emis_gain_lane<NT_>(b, m, iv, em, CS, WuV, st)
+      TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
+    } else {
+#define CALL(NT_) launch_emis_lane<NT_>(b, m, iv, em, vlane, flane && !fused_fb, glane, st)
+      TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+    }
     (void)hipEventRecord(b->ev[eV + 4], st);
     if (flane) {
       (void)hipEventRecord(b->evX[0], st);
@@ -1411,9 +1431,11 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     vc.ntie = sw.ntie.p; vc.ties = sw.ties.p; vc.tierows = sw.tierows.p; vc.segmin = sw.segmin.p;
     vc.offend = sw.offend.p; vc.clink = sw.clink.p; vc.clk = sw.clk.p;
     if (glane) {
+      if (!emis_gain) {
 #define CALL(NT_) launch_gain_lane<NT_>(b, m, iv, CS, WuV, st)
-      TEHMM_NT_DISPATCH(m->NP, CALL)
+        TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
+      }
       gain.resize((size_t)std::max(1, lw.n_groups) * 64);
       HIPCHK(hipMemcpyAsync(gain.data(), lw.vgain.p, gain.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     } else {

@@ -636,8 +636,11 @@ struct VitItems {
   double *piecemin;         // P2: [item][MAXTI + 1] lowest live value of each piece between ties
 };
 
+#ifndef TEHMM_P2_WAVES
+#define TEHMM_P2_WAVES 1
+#endif
 template <int NT, bool QUANT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TEHMM_P2_WAVES, TEHMM_P2_WAVES)))
 void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItems *vip, int N, int Wu, const int *wk_g,
                 const int *wk_e, int n_work, const double *__restrict__ tabs, int e0,
                 const double *__restrict__ B, uint8_t *tb) {
@@ -1073,6 +1076,85 @@ __global__ __launch_bounds__(256) void k_vit_gain_lane(IntervalTab iv, LaneGeom 
     for (int j = 0; j < NT / 2; ++j) W[j] = x[j] + (lane_f2){b[2 * j], b[2 * j + 1]};
   }
   if (run) gain[item] = bad ? __longlong_as_double(0x7ff8000000000000LL) : (double)vec_max() - (double)g0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Emission rows + P0 in ONE pass (round 2).  k_emis_lane wrote the log rows twice (fp64 for the exact pass,
+// rounded to float for P0) and k_vit_gain_lane read the float copy back: 297 bytes per position of HBM
+// traffic for a pass whose arithmetic fits under the row kernel's own stores.  Here the lane that computes
+// the rows of its item (reference operation order, _emission.pyx:65-72) feeds them, rounded to float, straight
+// into the packed-float max-plus recurrence of P0 -- starting Wu positions early for the warm-up (those rows
+// are recomputed, not stored: + Wu / L work).  Outputs: B (fp64 log rows, item-interleaved; NaN rows where no
+// state can emit) and gain[item] as k_vit_gain_lane.
+// ------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k_emis_gain_lane(IntervalTab iv, EmisTab em, LaneGeom lg, int N, int CS, int Wu,
+                                                        const float *__restrict__ tabf, double *B, double *gain) {
+  extern __shared__ double emis_ltab[];
+  stage_emis_table(em, emis_ltab, NT);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= lg.n_groups) return;
+  const int L = lg.L;
+  const int64_t item = (int64_t)g * 64 + lane;
+  const bool valid = item < lg.n_items;
+  const int id = valid ? lg.item_iv[item] : 0;
+  const int64_t t0 = valid ? lg.item_t0[item] : 0;
+  const int64_t T = iv.len[id], p0 = iv.pos0[id];
+  const int len = valid ? (int)min((int64_t)L, T - t0) : 0;
+  const int maxlen = wave_max_i32(len);
+  const int64_t ct0 = (t0 / CS) * CS;
+  const bool run = valid && ct0 > 0 && ct0 + CS <= T;       // P0 runs on full chunks but an interval's first
+  const int s_first = __any(run) ? -Wu : 0;
+  const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+  lane_f2 W[NT / 2];
+#pragma unroll
+  for (int j = 0; j < NT / 2; ++j)
+    W[j] = (lane_f2){2 * j < N ? 0.f : -INFINITY, 2 * j + 1 < N ? 0.f : -INFINITY};
+  bool bad = false;
+  auto vec_max = [&]() {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NT / 2; ++j) mx = fmaxf(mx, fmaxf(W[j].x, W[j].y));
+    return mx;
+  };
+  float g0 = 0.f;
+  for (int s = s_first; s < maxlen; ++s) {
+    const bool act = s >= 0 ? s < len : run;
+    const int64_t gpos = p0 + t0 + (act ? s : 0);
+    double x[NT];
+    emis_rows<NT>(em, emis_ltab, gpos, x);
+    double m = x[0];
+#pragma unroll
+    for (int j = 1; j < NT; ++j) m = fmax(m, j < N ? x[j] : -INFINITY);
+    const bool good = m > -1e20;
+    if (B && s >= 0 && act) {
+      const int64_t o = ((((int64_t)g * lg.L + s) * NT) << 6) + lane;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) B[o + ((int64_t)j << 6)] = good ? x[j] : qnan;
+    }
+    // ---- P0 step on the row rounded to float (see k_vit_gain_lane)
+    if (s == 0) g0 = vec_max();
+    bad = bad | (act && !good);
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    const_f2 *tp = (const_f2 *)(size_t)tabf + z;
+    lane_f2 xn[NT / 2];
+#pragma unroll
+    for (int op = 0; op < NT / 2; ++op) {
+      lane_f2 acc = (lane_f2){W[0].x, W[0].x} + tp[op * NT];
+#pragma unroll
+      for (int f = 1; f < NT; ++f) {
+        const float wf = (f & 1) ? W[f >> 1].y : W[f >> 1].x;
+        acc = __builtin_elementwise_max(acc, (lane_f2){wf, wf} + tp[op * NT + f]);
+      }
+      xn[op] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j < NT / 2; ++j) W[j] = xn[j] + (lane_f2){(float)x[2 * j], (float)x[2 * j + 1]};
+  }
+  if (run) gain[item] = (bad || len < L) ? qnan : (double)vec_max() - (double)g0;
 }
 
 }  // namespace tehmm

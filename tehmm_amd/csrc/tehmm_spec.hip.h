@@ -35,7 +35,9 @@
 namespace tehmm {
 
 #define TEHMM_SPEC_NONE (-2147483647 - 1)
+#ifndef TEHMM_SPEC_MIN_E
 #define TEHMM_SPEC_MIN_E 18          // speculate only where |V| >= 2^18 (room for the index bits)
+#endif
 
 struct VitChunks {
   const int *iv;          // chunk -> interval id
