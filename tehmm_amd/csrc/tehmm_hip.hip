@@ -1327,6 +1327,10 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   b->tpairs.clear();
   b->tms.clear();
   if (b->n == 0 || b->total == 0) return TEHMM_OK;
+#ifdef TEHMM_DEV_NT
+  if (m->N < 64 && m->NP != TEHMM_DEV_NT)
+    return fail(TEHMM_ERR_UNSUPPORTED, "development build: fused kernels exist for one padded state count only");
+#endif
   int rc = ensure_workspace(b, m, flags);
   if (rc) return rc;
   const bool ratio = (flags & TEHMM_EVAL_USE_RATIOS) && b->has_ratios;
@@ -1670,13 +1674,15 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     } else if (SPL == 1) launch_viterbi<1>(b, m, iv, em, ratio, st);
     else launch_viterbi<2>(b, m, iv, em, ratio, st);
     (void)hipEventRecord(b->ev[eV + 1], st);
+    allow_lds(k_tb_compose, 4 * TEHMM_TB_STAGE);
+    allow_lds(k_tb_fill, 4 * TEHMM_TB_STAGE);
     if (b->n_chunks > 0)
-      hipLaunchKernelGGL(k_tb_compose, dim3(b->n_chunks), dim3(64), 0, st, iv, b->d_chunk_iv.p,
-                         b->d_chunk0.p, m->N, m->NP, b->TBW, b->tb.p, b->G.p);
+      hipLaunchKernelGGL(k_tb_compose, dim3((b->n_chunks + 3) / 4), dim3(256), 4 * tb_stage_bytes(b->TBW), st, iv, b->d_chunk_iv.p,
+                         b->d_chunk0.p, b->n_chunks, m->N, m->NP, b->TBW, b->tb.p, b->G.p);
     hipLaunchKernelGGL(k_tb_scan, dim3(std::max(1, b->n)), dim3(64), 0, st, iv, b->d_chunk0.p, m->NP,
                        b->G.p, b->last_state.p, b->bstate.p, b->paths.p);
     if (b->n_chunks > 0)
-      hipLaunchKernelGGL(k_tb_fill, dim3(grid_for(b->n_chunks, 64, 1 << 30)), dim3(64), 0, st, iv,
+      hipLaunchKernelGGL(k_tb_fill, dim3((b->n_chunks + 3) / 4), dim3(256), 4 * tb_stage_bytes(b->TBW), st, iv,
                          b->n_chunks, b->d_chunk_iv.p, b->d_chunk0.p, b->TBW, b->tb.p, b->bstate.p,
                          b->paths.p);
     (void)hipEventRecord(b->ev[eV + 2], st);
@@ -1986,13 +1992,15 @@ int tehmm_viterbi(int64_t T, int N, const double *pi, const double *lt, const do
     if (segRatios) { VIT_LAUNCH(2, true); } else { VIT_LAUNCH(2, false); }
   }
 #undef VIT_LAUNCH
+  allow_lds(k_tb_compose, 4 * TEHMM_TB_STAGE);
+  allow_lds(k_tb_fill, 4 * TEHMM_TB_STAGE);
   if (nch > 0)
-    hipLaunchKernelGGL(k_tb_compose, dim3(nch), dim3(64), 0, 0, iv, d_chunk_iv.p, d_chunk0.p, N, NP, NP,
-                       d_tb.p, d_G.p);
+    hipLaunchKernelGGL(k_tb_compose, dim3((nch + 3) / 4), dim3(256), 4 * tb_stage_bytes(NP), 0, iv, d_chunk_iv.p, d_chunk0.p,
+                       nch, N, NP, NP, d_tb.p, d_G.p);
   hipLaunchKernelGGL(k_tb_scan, dim3(1), dim3(64), 0, 0, iv, d_chunk0.p, NP, d_G.p, d_last.p, d_bs.p,
                      d_paths.p);
   if (nch > 0)
-    hipLaunchKernelGGL(k_tb_fill, dim3(grid_for(nch, 64, 1 << 30)), dim3(64), 0, 0, iv, nch,
+    hipLaunchKernelGGL(k_tb_fill, dim3((nch + 3) / 4), dim3(256), 4 * tb_stage_bytes(NP), 0, iv, nch,
                        d_chunk_iv.p, d_chunk0.p, NP, d_tb.p, d_bs.p, d_paths.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(path, d_paths.p, (size_t)T * sizeof(int64_t), hipMemcpyDeviceToHost));
@@ -2038,6 +2046,10 @@ void launch_estep(const tehmm_model *m, const IntervalTab &iv, const EmisTab &em
 // after its first emittable one (the reference's lattices are NaN there).
 static int estep_accumulate(tehmm_model_t *m, tehmm_batch_t *b, int use_ratios, double *dev_stats, double *lp_out,
                             int *dead_out) {
+#ifdef TEHMM_DEV_NT
+  if (m->NP != TEHMM_DEV_NT)
+    return fail(TEHMM_ERR_UNSUPPORTED, "development build: fused kernels exist for one padded state count only");
+#endif
   *lp_out = 0.0;
   *dead_out = 0;
   b->h_fwd_lp.assign((size_t)b->n, 0.0);
