@@ -22,8 +22,19 @@ def hipcc():
     return "hipcc"
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+STAMP = LIB + ".flags"      # the flags the in-tree library was built with (a development build is rebuilt)
+
+
+def _built_flags():
+    try:
+        with open(STAMP) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def needs_build(flags=""):
+    if not os.path.exists(LIB) or _built_flags() != flags:
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(d) > t for d in DEPS if os.path.exists(d))
@@ -33,15 +44,20 @@ def build(force=False, verbose=False, dev_nt=None):
     """dev_nt (or TEHMM_DEV_NT in the environment): development build for ONE padded state count
     (fast to compile; every other N then fails with TEHMM_ERR_UNSUPPORTED-like silence -- never ship it)."""
     dev_nt = dev_nt or os.environ.get("TEHMM_DEV_NT")
-    if not force and not needs_build() and not dev_nt:
+    flags = "-DTEHMM_DEV_NT=%d" % int(dev_nt) if dev_nt else ""
+    if not force and not needs_build(flags):
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
            "-std=c++17", "-Wall", "-Wno-unused-function", "-o", LIB] + SOURCES
     if dev_nt:
-        cmd.insert(1, "-DTEHMM_DEV_NT=%d" % int(dev_nt))
+        cmd.insert(1, flags)
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
+    if os.path.exists(STAMP):
+        os.remove(STAMP)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(flags + "\n")
     return LIB
 
 

@@ -299,6 +299,9 @@ __global__ void k_model_layouts(int NP, const double *lt, double *ltT, double *A
   AG[tg] = a;
   ATG[tgT] = a;                                  // group-major copy of A^T: entry [from = o][out = f]
   ltP[((o >> 1) * NP + f) * 2 + (o & 1)] = (float)l;
+  // behind the table: lt[o][o] per output (pads 0) and lt[0][0], for the segment-ratio terms of P0
+  if (f == o) ltP[NP * NP + o] = l > -INFINITY ? (float)l : 0.f;
+  if (idx == 0) ltP[NP * NP + NP] = (float)l;
 }
 
 // the LDS-staged copy of the small tracks' rows

@@ -514,9 +514,11 @@ int tehmm_model_create(int N, int K, int S, const double *lt, const double *pi,
   };
   const std::vector<double> hltG = group_major(hlt), hAG = group_major(hA), hATG = group_major(hAT);
   hipError_t e = m->lt.upload(hlt.data(), hlt.size());
-  std::vector<float> hltP((size_t)NP * NP);
+  std::vector<float> hltP((size_t)NP * NP + NP + 2, 0.f);    // + lt[o][o] per output and lt[0][0] (segment-ratio P0)
   for (int f = 0; f < NP; ++f)
     for (int o = 0; o < NP; ++o) hltP[((size_t)(o >> 1) * NP + f) * 2 + (o & 1)] = (float)hlt[(size_t)f * NP + o];
+  for (int o = 0; o < N; ++o) hltP[(size_t)NP * NP + o] = (float)hlt[(size_t)o * NP + o];
+  hltP[(size_t)NP * NP + NP] = (float)hlt[0];
   if (e == hipSuccess) e = m->ltG.upload(hltG.data(), hltG.size());
   if (e == hipSuccess) e = m->ltP.upload(hltP.data(), hltP.size());
   if (e == hipSuccess) e = m->AG.upload(hAG.data(), hAG.size());
@@ -852,10 +854,16 @@ static void spec_assign_binades(const tehmm_batch *b, const std::vector<double> 
       const double margin = 512.0 + rel * std::fabs(ve);
       const double lo = std::fabs(vs) - margin, hi = std::fabs(ve) + margin;
       if (!(lo > 0.0)) continue;
-      int ex = 0;
+      int ex = 0, exh = 0;
       (void)std::frexp(lo, &ex);          // lo = f * 2^ex, f in [0.5, 1)  ->  binade exponent ex - 1
-      const int be = ex - 1;
-      if (be < TEHMM_SPEC_MIN_E || !(hi < std::ldexp(1.0, be + 1))) continue;
+      (void)std::frexp(hi, &exh);
+      // A chunk that crosses into the next binade is quantised for the binade it ends in: the exact chain
+      // runs it up to the crossing and is then verified against its rows like anywhere else (the check
+      // demands every live value inside the binade, so nothing before the crossing is ever adopted).
+      static const bool cross = !(std::getenv("TEHMM_SPEC_CROSS") && std::atoi(std::getenv("TEHMM_SPEC_CROSS")) == 0);
+      if (exh != ex && !(cross && exh == ex + 1)) continue;
+      const int be = exh - 1;
+      if (be < TEHMM_SPEC_MIN_E) continue;
       e[(size_t)c] = be;
     }
   }
@@ -879,16 +887,25 @@ static void launch_vit_spec(tehmm_batch *b, const tehmm_model *m, const Interval
 
 template <int NT>
 static void launch_vit_fix(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em,
-                           const VitChunks &vc, bool segmin, hipStream_t st) {
+                           const VitChunks &vc, bool segmin, bool ratio, hipStream_t st) {
   size_t lds = ((size_t)3 * 32 * (NT + 1) + 2 * 33 * (NT + 2) + (size_t)m->lds_rows * NT + 8) * sizeof(double);   // CPB = 32
   allow_lds(k_vit_fix<NT, false>, lds);
   allow_lds(k_vit_fix<NT, true>, lds);
+  if constexpr (NT <= 36) if (ratio) {
+    allow_lds(k_vit_fix<NT, true, true>, lds);
+    hipLaunchKernelGGL((k_vit_fix<NT, true, true>), dim3(b->n), dim3(256), lds, st, iv, em, vc, m->N, m->lt.p,
+                       m->ltT.p, m->pi.p, b->tb.p, b->last_state.p, b->vit_lp.p, b->sw.stats.p,
+                       (const double *)b->ratios.p);
+    return;
+  }
   if (segmin)
     hipLaunchKernelGGL((k_vit_fix<NT, true>), dim3(b->n), dim3(256), lds, st, iv, em, vc, m->N, m->lt.p,
-                       m->ltT.p, m->pi.p, b->tb.p, b->last_state.p, b->vit_lp.p, b->sw.stats.p);
+                       m->ltT.p, m->pi.p, b->tb.p, b->last_state.p, b->vit_lp.p, b->sw.stats.p,
+                       (const double *)nullptr);
   else
     hipLaunchKernelGGL((k_vit_fix<NT, false>), dim3(b->n), dim3(256), lds, st, iv, em, vc, m->N, m->lt.p,
-                       m->ltT.p, m->pi.p, b->tb.p, b->last_state.p, b->vit_lp.p, b->sw.stats.p);
+                       m->ltT.p, m->pi.p, b->tb.p, b->last_state.p, b->vit_lp.p, b->sw.stats.p,
+                       (const double *)nullptr);
 }
 
 // ---- lane = item passes -----------------------------------------------------------------------
@@ -1028,9 +1045,43 @@ static bool quantised_table(const tehmm_model *m, int e, double *out) {
   return ok;
 }
 
+// The same with one header block per output group for the segment-ratio terms (k_vit_lane<.., RATIO>): lt[o][o]
+// of the group's four outputs (unrounded: the product with the ratio is rounded per position) and R_u(lt[0][0]).
+static size_t quantised_table_size(const tehmm_model *m, bool ratio) {
+  return (size_t)m->NP * m->NP + (ratio ? (size_t)(m->NP / 4) * 16 : 0);
+}
+static bool quantised_table_ratio(const tehmm_model *m, int e, double *out) {
+  const int N = m->N, NP = m->NP;
+  std::vector<double> plain((size_t)NP * NP);
+  bool ok = quantised_table(m, e, plain.data());
+  const double u = std::ldexp(1.0, e - 52), M = std::ldexp(1.5, e), half_u = 0.5 * u;
+  const double z = m->h_lt[0];
+  volatile double zm = z + M;
+  const double q00 = zm - M;
+  if (std::fabs(z - q00) == half_u) ok = false;
+  for (int og = 0; og < NP / 4; ++og) {
+    double *grp = out + (size_t)og * (NP * 4 + 16);
+    for (int i = 0; i < 16; ++i) grp[i] = 0.0;
+    for (int q = 0; q < 4; ++q) {
+      const int o = 4 * og + q;
+      grp[q] = o < N ? m->h_lt[(size_t)o * N + o] : 0.0;
+    }
+    grp[4] = q00;
+    std::memcpy(grp + 16, plain.data() + (size_t)og * NP * 4, (size_t)NP * 4 * sizeof(double));
+  }
+  return ok;
+}
+// segment ratios on the chunk-parallel path need finite self-transitions (a -inf one makes the products NaN
+// or -inf in ways the quantised arithmetic does not mirror; the sequential kernels handle those models)
+static bool ratio_lane_ok(const tehmm_model *m) {
+  for (int o = 0; o < m->N; ++o)
+    if (!std::isfinite(m->h_lt[(size_t)o * m->N + o])) return false;
+  return true;
+}
+
 template <int NT>
 static void launch_vit_lane(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const VitChunks &vc,
-                            bool quant, int Wu, int n_work, int e0, hipStream_t st) {
+                            bool quant, bool ratio, int Wu, int n_work, int e0, hipStream_t st) {
   LaneWork &lw = b->lw;
   const LaneGeom lg = lane_geom(lw);
   const VitItems vi = lane_vit_items(lw);
@@ -1040,11 +1091,18 @@ static void launch_vit_lane(tehmm_batch *b, const tehmm_model *m, const Interval
   (void)lw.d_vc.fill_async(&lw.hs_vc, 1, st);
   (void)lw.d_vi.fill_async(&lw.hs_vi, 1, st);
   const dim3 grid((n_work + 3) / 4);
+  if constexpr (NT <= 36) if (quant && ratio) {
+    hipLaunchKernelGGL((k_vit_lane<NT, true, true>), grid, dim3(256), 0, st, iv, lg, (const VitChunks *)lw.d_vc.p,
+                       (const VitItems *)lw.d_vi.p, m->N, Wu,
+                       (const int *)lw.wk_g.p, (const int *)lw.wk_e.p, n_work, (const double *)lw.qtabs.p, e0,
+                       (const double *)lw.B.p, b->tb.p, (const double *)b->ratios.p);
+    return;
+  }
   if (quant) {
     hipLaunchKernelGGL((k_vit_lane<NT, true>), grid, dim3(256), 0, st, iv, lg, (const VitChunks *)lw.d_vc.p,
                        (const VitItems *)lw.d_vi.p, m->N, Wu,
                        (const int *)lw.wk_g.p, (const int *)lw.wk_e.p, n_work, (const double *)lw.qtabs.p, e0,
-                       (const double *)lw.B.p, b->tb.p);
+                       (const double *)lw.B.p, b->tb.p, (const double *)nullptr);
   }
 }
 
@@ -1083,12 +1141,19 @@ static void launch_emis_lane(tehmm_batch *b, const tehmm_model *m, const Interva
 // emission rows (fp64 log rows for the exact Viterbi pass) and P0 in one pass
 template <int NT>
 static void launch_emis_gain_lane(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em,
-                                  int CS, int Wu, hipStream_t st) {
+                                  int CS, int Wu, bool ratio, hipStream_t st) {
   LaneWork &lw = b->lw;
   const size_t lds = (size_t)em.lds_rows * NT * sizeof(double);
+  if constexpr (NT <= 36) if (ratio) {
+    allow_lds(k_emis_gain_lane<NT, true>, lds);
+    hipLaunchKernelGGL((k_emis_gain_lane<NT, true>), dim3((lw.n_groups + 3) / 4), dim3(256), lds, st, iv, em,
+                       lane_geom(lw), m->N, CS, Wu, (const float *)m->ltP.p, lw.B.p, lw.vgain.p,
+                       (const double *)b->ratios.p);
+    return;
+  }
   allow_lds(k_emis_gain_lane<NT>, lds);
   hipLaunchKernelGGL((k_emis_gain_lane<NT>), dim3((lw.n_groups + 3) / 4), dim3(256), lds, st, iv, em, lane_geom(lw),
-                     m->N, CS, Wu, (const float *)m->ltP.p, lw.B.p, lw.vgain.p);
+                     m->N, CS, Wu, (const float *)m->ltP.p, lw.B.p, lw.vgain.p, (const double *)nullptr);
 }
 
 template <int NT>
@@ -1344,7 +1409,10 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   const int CS = spec_chunk_size();
   const bool spec_ok = coop && CS > 0 && m->NP <= 64 && b->total >= 2 * (int64_t)CS;
   const bool vit = flags & TEHMM_EVAL_VITERBI, postr = flags & TEHMM_EVAL_POSTERIOR;
-  const bool vspec = vit && spec_ok && !ratio, fspec = postr && spec_ok;
+  // segment ratios: the chunk-parallel Viterbi path takes them in its lane = item form only (finite
+  // self-transitions, NP <= 36, the fused P0 pass); otherwise the sequential kernels
+  bool vspec = vit && spec_ok && (!ratio || (ratio_lane_ok(m) && m->NP <= 36));
+  const bool fspec = postr && spec_ok;
   if (vspec || fspec) {
     rc = spec_prepare(b, m, CS);
     if (rc) return rc;
@@ -1380,6 +1448,10 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     if ((double)b->total * m->NP * 8.0 * 1.6 > 0.85 * (double)free_b) b->lw.no_vlane = true;
   }
   if (b->lw.no_vlane) want_vlane = false;
+  if (ratio && vspec && !(LS > 0 && want_vlane && (fused_fb || !(fspec && LS > 0)))) {
+    vspec = false;                                    // no lane passes for this call: sequential Viterbi with ratios
+    if (!fspec) LS = 0;
+  }
   const bool vlane = vspec && LS > 0 && want_vlane, flane = fspec && LS > 0;
   // P0 (binade placement) as a packed-float lane pass over float emission rows; TEHMM_LANE_P0=0 keeps
   // the fp64 lane = state pass
@@ -1412,7 +1484,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     // emission rows of every position, once, item-interleaved (log rows for Viterbi, linear for fwd/bwd)
     hipStream_t st = b->sV;
     if (emis_gain) {
-#define CALL(NT_) launch_emis_gain_lane<NT_>(b, m, iv, em, CS, WuV, st)
+#define CALL(NT_) launch_emis_gain_lane<NT_>(b, m, iv, em, CS, WuV, ratio, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
     } else {
@@ -1581,11 +1653,13 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       wk_g.clear();
       wk_e.clear();
       if (emin <= emax) {
-        const size_t tsz = (size_t)m->NP * m->NP;
+        const size_t tsz = quantised_table_size(m, ratio);
         std::vector<double> &qt = lw.hs_qt;
         qt.resize((size_t)(emax - emin + 1) * tsz);
         std::vector<char> eok((size_t)(emax - emin + 1), 1);
-        for (int e = emin; e <= emax; ++e) eok[(size_t)(e - emin)] = quantised_table(m, e, qt.data() + (size_t)(e - emin) * tsz);
+        for (int e = emin; e <= emax; ++e)
+          eok[(size_t)(e - emin)] = ratio ? quantised_table_ratio(m, e, qt.data() + (size_t)(e - emin) * tsz)
+                                          : quantised_table(m, e, qt.data() + (size_t)(e - emin) * tsz);
         for (int c = 0; c < sw.n_chunks; ++c)
           if (he[(size_t)c] != TEHMM_SPEC_NONE && !eok[(size_t)(he[(size_t)c] - emin)]) he[(size_t)c] = TEHMM_SPEC_NONE;
         HIPCHK(lw.qtabs.fill_async(qt.data(), qt.size(), st));
@@ -1625,7 +1699,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       HIPCHK(hipMemsetAsync(sw.stats.p, 0, 2 * sizeof(int), st));
       HIPCHK(hipMemsetAsync(lw.vbad.p, 0, (size_t)std::max(1, lw.n_groups) * 64 * sizeof(int), st));
       HIPCHK(hipMemsetAsync(lw.vntie.p, 0, (size_t)std::max(1, lw.n_groups) * 64 * sizeof(int), st));
-#define CALL(NT_) launch_vit_lane<NT_>(b, m, iv, vc, true, WuV, n_work, emin, st)
+#define CALL(NT_) launch_vit_lane<NT_>(b, m, iv, vc, true, ratio, WuV, n_work, emin, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
 
@@ -1638,7 +1712,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
         rc = enqueue_posterior();
         if (rc) return rc;
       }
-#define CALL(NT_) launch_vit_fix<NT_>(b, m, iv, em, vc, true, st)
+#define CALL(NT_) launch_vit_fix<NT_>(b, m, iv, em, vc, true, ratio, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
     } else if (vspec) {
@@ -1664,7 +1738,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
         rc = enqueue_posterior();
         if (rc) return rc;
       }
-#define CALL(NT_) launch_vit_fix<NT_>(b, m, iv, em, vc, false, st)
+#define CALL(NT_) launch_vit_fix<NT_>(b, m, iv, em, vc, false, false, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
     } else if (coop) {

@@ -639,11 +639,19 @@ struct VitItems {
 #ifndef TEHMM_P2_WAVES
 #define TEHMM_P2_WAVES 1
 #endif
-template <int NT, bool QUANT>
+// RATIO (round 2): segment ratios on the transitions (decode on a segmented TrackTable, _hmm.pyx:229-247).  Inside a
+// binade every separately rounded addend of the reference's sums is just another grid-rounded term:
+//   from >= 1:  ((V + lt) + b) + lt[to][to] * (r - 1)  [if r > 1]     =  V + R(lt) + R(b) + R(z1)
+//   from == 0:  ((V + lt) + b) + lt[to][to] * r  [- lt[0][0] if to == 0] = V + R(lt) + R(b) + R(z0) [- R(lt00)]
+// (the from-state-0 quirk Q4).  So the candidates from >= 1 share the offset R(z1) and candidate 0 carries the
+// difference d0 = R(z0) - R(z1) - [to == 0] R(lt00), a multiple of u: the table stream gets one header block per
+// output group with lt[to][to] of its four outputs (and R(lt00)), the products are formed and rounded per
+// position, and a product that lands exactly between two grid points is a rounding tie like one of b.
+template <int NT, bool QUANT, bool RATIO = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TEHMM_P2_WAVES, TEHMM_P2_WAVES)))
 void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItems *vip, int N, int Wu, const int *wk_g,
                 const int *wk_e, int n_work, const double *__restrict__ tabs, int e0,
-                const double *__restrict__ B, uint8_t *tb) {
+                const double *__restrict__ B, uint8_t *tb, const double *__restrict__ ratios = nullptr) {
   const int lane = threadIdx.x & 63;
   const int wk = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wave-uniform
   if (wk >= n_work) return;
@@ -665,12 +673,14 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItem
   if (QUANT) run = run && vcp->e[c] == e;
   if (!__any(run)) return;
   const int64_t nb = run ? item - 1 : item;
-  const_f64 *tab0 = (const_f64 *)(size_t)tabs + (QUANT ? (int64_t)(e - e0) * NT * NT : 0);
+  constexpr int TABSZ = RATIO ? NT * NT + (NT / 4) * 16 : NT * NT;      // RATIO: + one header block per output group
+  const_f64 *tab0 = (const_f64 *)(size_t)tabs + (QUANT ? (int64_t)(e - e0) * TABSZ : 0);
   const double u = QUANT ? ldexp(1.0, e - 52) : 0.0;
   const double M = QUANT ? ldexp(1.5, e) : 0.0;          // fl(z + M) - M rounds z to the grid u
   const double half_u = 0.5 * u;
   const double inv_u = QUANT ? ldexp(1.0, 52 - e) : 0.0;
   const double wlim = QUANT ? -ldexp(1.0, e + 1) : -INFINITY;
+  const double zlim = QUANT ? ldexp(1.0, e - 1) : INFINITY;
   double W[NT];                                          // QUANT: 64 x (value - base); plain: value
 #pragma unroll
   for (int j = 0; j < NT; ++j) W[j] = j < N ? 0.0 : -INFINITY;
@@ -697,24 +707,52 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItem
 #pragma unroll
     for (int q = 0; q < 4; ++q) bnx[q] = row[(int64_t)(4 * og + q) << 6];
   };
-  auto step = [&](const double *bp, const double *bpn, int s) {
+  auto step = [&](const double *bp, const double *bpn, int s, double rt) {
     const bool official = s >= 0;
     double tmin = 1.0;
     // the max-plus recurrence as a pinned software pipeline over the scalar stream (see k_fb_lane)
     const_f64 *tp = tab0;
     asm volatile("" : "+s"(tp));
-    constexpr int BLK = 16, NB = NT * NT / BLK;
+    constexpr int BLK = 16, GB = NT / 4 + (RATIO ? 1 : 0), NB = (NT / 4) * GB;   // blocks per output group, in all
     double t[2][BLK];
 #pragma unroll
     for (int i = 0; i < BLK; ++i) t[0][i] = tp[i];
     double Wn[NT];
     double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
     double bc[4];
+    double d0[4] = {0.0, 0.0, 0.0, 0.0}, zq1[4] = {0.0, 0.0, 0.0, 0.0};      // RATIO: per output of the group
+    const bool rgt = RATIO && rt > 1.0;
+    const double rm1 = rt - 1.0;
 #pragma clang loop unroll(full)
     for (int b = 0; b < NB; ++b) {
-      const int og = (b * 4) / NT, f0 = (b * 4) % NT;
+      const int og = b / GB, f0 = RATIO ? ((b % GB) - 1) * 4 : (b % GB) * 4;
       const double *tc = t[b & 1];
       double *tn = t[(b + 1) & 1];
+      if (RATIO && f0 < 0) {
+        // header block of the group: tc[q] = lt[o][o] of its outputs o = 4 og + q, tc[4] = R_u(lt[0][0])
+        const_f64 *tq = tp;
+        asm volatile("" : "+s"(tq) : "v"(x0));
+        if (b + 1 < NB) {
+#pragma unroll
+          for (int i = 0; i < BLK; ++i) tn[i] = tq[(b + 1) * BLK + i];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double z0 = tc[q] * rt;
+          const double q0 = (z0 + M) - M;
+          bad = bad | !(fabs(z0) < zlim);                      // fl(z + M) - M needs |z| < 2^(e-1)
+          tmin = fmin(tmin, fabs(fabs(z0 - q0) - half_u));
+          const double z1 = tc[q] * rm1;
+          const double q1r = (z1 + M) - M;
+          // (r <= 1: the term is absent; its tie test is neutralised with the distance 1.0)
+          tmin = fmin(tmin, rgt ? fabs(fabs(z1 - q1r) - half_u) : 1.0);
+          const double q1 = rgt ? q1r : 0.0;
+          zq1[q] = q1;
+          d0[q] = (q0 - q1) - ((4 * og + q == 0) ? tc[4] : 0.0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
       if (f0 == 0) {
         // x = max_f W[f] + tab[f][o]   (tab scalar; QUANT: it carries the from-index in its low bits)
 #pragma unroll
@@ -722,6 +760,7 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItem
         if (og + 1 < NT / 4) prefetch(bp, og + 1);
         else prefetch(bpn, 0);
         x0 = W[0] + tc[0];
+        if (RATIO) x0 += 64.0 * d0[0];
       } else {
         x0 = fmax(x0, W[f0] + tc[0]);
       }
@@ -735,6 +774,11 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItem
         x1 = W[0] + tc[1];
         x2 = W[0] + tc[2];
         x3 = W[0] + tc[3];
+        if (RATIO) {
+          x1 += 64.0 * d0[1];
+          x2 += 64.0 * d0[2];
+          x3 += 64.0 * d0[3];
+        }
       } else {
         x1 = fmax(x1, W[f0] + tc[1]);
         x2 = fmax(x2, W[f0] + tc[2]);
@@ -769,7 +813,7 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItem
           const double r = k - 64.0 * floor(k * 0.015625);     // k mod 64 in [0, 63]
           const int arg = 63 - (int)r;
           // a dead state (m = -inf) makes r NaN: maxNum(NaN, -inf) puts -inf back without a branch
-          Wn[o] = fmax((m - r * u) + 64.0 * bq, -INFINITY);
+          Wn[o] = fmax((m - r * u) + 64.0 * (RATIO ? bq + zq1[q] : bq), -INFINITY);
           pw |= (uint32_t)(arg & 63) << (8 * q);
         } else {
           Wn[o] = xs[q] + bo;
@@ -857,7 +901,7 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItem
     return mx;
   };
 
-  double g0 = 0.0;
+  double g0 = 0.0, rnx = 1.0;
   for (int s = -Wu; s < L; ++s) {                       // one loop: the unrolled step exists once
     close_piece(s);
     if (s == 0) {
@@ -869,7 +913,14 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItem
     const int sn = min(s + 1, L - 1);
     const double *bpn = B + (sn < 0 ? lane_row(lg, NT, nb, L + sn) : lane_row(lg, NT, item, sn));
     if (s == -Wu) prefetch(bp, 0);
-    step(bp, bpn, s);
+    double rt = 1.0;
+    if (RATIO) {
+      // (positions t0 + s of the interval: the warm-up reads the previous item's; one step ahead)
+      if (s == -Wu) rnx = run ? ratios[p0 + t0 + s] : 1.0;
+      rt = rnx;
+      rnx = (run && s + 1 < L) ? ratios[p0 + t0 + s + 1] : 1.0;
+    }
+    step(bp, bpn, s, rt);
     if (((s + Wu) & (TEHMM_VROW - 1)) == TEHMM_VROW - 1) rebase(s, ((s + Wu) & 31) == 31);
   }
   close_piece(L);
@@ -1087,9 +1138,10 @@ __global__ __launch_bounds__(256) void k_vit_gain_lane(IntervalTab iv, LaneGeom 
 // are recomputed, not stored: + Wu / L work).  Outputs: B (fp64 log rows, item-interleaved; NaN rows where no
 // state can emit) and gain[item] as k_vit_gain_lane.
 // ------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, bool RATIO = false>
 __global__ __launch_bounds__(256) void k_emis_gain_lane(IntervalTab iv, EmisTab em, LaneGeom lg, int N, int CS, int Wu,
-                                                        const float *__restrict__ tabf, double *B, double *gain) {
+                                                        const float *__restrict__ tabf, double *B, double *gain,
+                                                        const double *__restrict__ ratios = nullptr) {
   extern __shared__ double emis_ltab[];
   stage_emis_table(em, emis_ltab, NT);
   __syncthreads();
@@ -1141,9 +1193,20 @@ __global__ __launch_bounds__(256) void k_emis_gain_lane(IntervalTab iv, EmisTab 
     asm volatile("" : "+s"(z));
     const_f2 *tp = (const_f2 *)(size_t)tabf + z;
     lane_f2 xn[NT / 2];
+    // RATIO: the self-transition terms of the segment ratio (see k_vit_lane); tabf carries lt[o][o] behind the table
+    float rf = 1.f, rm1 = 0.f;
+    if (RATIO) {
+      rf = (float)ratios[gpos];
+      rm1 = rf > 1.f ? rf - 1.f : 0.f;
+    }
 #pragma unroll
     for (int op = 0; op < NT / 2; ++op) {
       lane_f2 acc = (lane_f2){W[0].x, W[0].x} + tp[op * NT];
+      if (RATIO) {
+        const lane_f2 ltd = tp[NT * NT / 2 + op];
+        acc = acc + ltd * (lane_f2){rf - rm1, rf - rm1};
+        if (op == 0) acc.x -= ((const float *)(size_t)tabf)[z + NT * NT + NT];
+      }
 #pragma unroll
       for (int f = 1; f < NT; ++f) {
         const float wf = (f & 1) ? W[f >> 1].y : W[f >> 1].x;
@@ -1152,7 +1215,10 @@ __global__ __launch_bounds__(256) void k_emis_gain_lane(IntervalTab iv, EmisTab 
       xn[op] = acc;
     }
 #pragma unroll
-    for (int j = 0; j < NT / 2; ++j) W[j] = xn[j] + (lane_f2){(float)x[2 * j], (float)x[2 * j + 1]};
+    for (int j = 0; j < NT / 2; ++j) {
+      W[j] = xn[j] + (lane_f2){(float)x[2 * j], (float)x[2 * j + 1]};
+      if (RATIO) W[j] = W[j] + tp[NT * NT / 2 + j] * (lane_f2){rm1, rm1};
+    }
   }
   if (run) gain[item] = (bad || len < L) ? qnan : (double)vec_max() - (double)g0;
 }

@@ -228,11 +228,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // ------------------------------------------------------------------------------------------
 // SEGMIN: the chunk data come from the lane passes (tehmm_lane.hip.h): "stays in the binade up to the
 // segment end" is decided from the segment's recorded minimum instead of the P0 gain estimate.
-template <int NT, bool SEGMIN>
+// RATIO: segment ratios on the transitions, in the reference's operation order incl. its from-state-0 quirk
+// (_hmm.pyx:229-247, quirk Q4; same arithmetic as k_vit_coop<NT, CPB, true>).
+template <int NT, bool SEGMIN, bool RATIO = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_lt,
                const double *g_ltT, const double *g_pi, uint8_t *tb, int *last_state,
-               double *logprob, int *stats) {
+               double *logprob, int *stats, const double *tratios = nullptr) {
   extern __shared__ double sm[];
   constexpr int RS = NT + 1;
   constexpr int VS = NT + 2;
@@ -272,6 +274,8 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
     double ltc[NT];
 #pragma unroll
     for (int f = 0; f < NT; ++f) ltc[f] = live ? g_lt[f * NT + jl] : -INFINITY;
+    const double ltd = live ? g_lt[jl * NT + jl] : 0.0;
+    const double lt00 = g_lt[0];
     const double pij = live ? g_pi[jl] : -INFINITY;
     const int vslot = lane < NT ? lane : NT + 1;
     double vcur = -INFINITY;
@@ -343,22 +347,30 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
         for (int p = 0; p < np; ++p) {
           const int64_t t = cur + p;
           const double b = br[p * RS + jl];
+          double r = 0.0;
+          if (RATIO) r = tratios[p0 + t];
           double v;
           if (t == 0) {
             v = pij + b;
+            if (RATIO && r > 1.) v += ltd * (r - 1.);
           } else {
             double rr[(NT + 15) / 16];
             rep_rows<NT>(vcur, rr);
             double x[NT];
             BcastAdd<0, NT>::run(rr, ltc, x);
-            const double c0 = x[0] + b;
+            double c0 = x[0] + b;
             x[0] = -INFINITY;
 #pragma unroll
             for (int n = NT; n > 1; n = (n + 1) / 2) {
 #pragma unroll
               for (int i = 0; i < n / 2; ++i) x[i] = fmax(x[i], x[i + (n + 1) / 2]);
             }
-            const double c1 = x[0] + b;
+            if (RATIO) {
+              c0 += ltd * r;
+              if (lane == 0) c0 -= lt00;
+            }
+            double c1 = x[0] + b;
+            if (RATIO && r > 1.) c1 += ltd * (r - 1.);
             v = c1 > c0 ? c1 : c0;
           }
           vcur = v;
@@ -427,6 +439,7 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
     // ============================================================== exact arg-max of the PREVIOUS block
     const int half = (N + 1) / 2;
     const int to_lo = (w - 2) * half, to_hi = min(N, to_lo + half);
+    const double lt00 = g_lt[0];
     for (int it = 0;; ++it) {
       const int64_t cur = seqpos[it & 3];
       const int64_t prev = it > 0 ? seqpos[(it - 1) & 3] : T;
@@ -444,6 +457,9 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
         for (int f2 = 0; f2 < NT / 2; ++f2) pv[f2] = vp[f2];
         const double *vnext = Vr + (pl + 1) * VS;
         const double *brow = br + pl * RS;
+        double r = 0.0;
+        if (RATIO) r = tratios[p0 + t];
+        const bool rg = RATIO && r > 1.;
         for (int to = to_lo; to < to_hi; ++to) {
           const double *lc = g_ltT + to * NT;
           const double vt = vnext[to];
@@ -453,6 +469,14 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
           for (int f2 = 0; f2 < NT / 2; ++f2) {
             c[2 * f2] = (pv[f2].x + lc[2 * f2]) + b;
             c[2 * f2 + 1] = (pv[f2].y + lc[2 * f2 + 1]) + b;
+          }
+          if (RATIO) {
+            const double ld = lc[to];
+            c[0] += ld * r;
+            if (to == 0) c[0] -= lt00;
+            const double addr = rg ? ld * (r - 1.) : 0.0;   // x + 0.0 == x for the equality below
+#pragma unroll
+            for (int f = 1; f < NT; ++f) c[f] += addr;
           }
           int arg = 0;
 #pragma unroll

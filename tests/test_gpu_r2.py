@@ -339,6 +339,90 @@ def test_long_interval_model_variants_vs_oracle(variant):
     assert res["viterbi_logprob"][0] == lp_o
 
 
+SPEC_ENV = ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_LANE_VIT", "TEHMM_LANE_P0",
+            "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS", "TEHMM_VIT_RUNS", "TEHMM_FUSED")
+
+
+def _mixed_ratios(T, seed, big=False):
+    """Segment ratios as a segmented table yields them: runs of 1.0 (unsegmented stretches), values above
+    and below 1, and -- big -- segments long enough that lt[j][j] * (r - 1) moves the score by hundreds."""
+    from tehmm_amd import synth
+    rs = np.random.RandomState(seed)
+    r = synth.random_ratios(T, seed=seed)
+    r[rs.rand(T) < 0.4] = 1.0
+    if big:
+        idx = rs.randint(0, T, size=max(1, T // 500))
+        r[idx] = rs.randint(200, 5000, size=idx.size).astype(np.float64) / 20.0
+    return np.ascontiguousarray(r)
+
+
+@pytest.mark.parametrize("N,env,big", [
+    (35, {"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "64"}, False),
+    (35, {"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "64", "TEHMM_VIT_RUNS": "0"}, True),
+    (35, {"TEHMM_SPEC_CHUNK": "1024"}, True),
+    (20, {"TEHMM_SPEC_CHUNK": "512", "TEHMM_LANE_SUB": "128"}, False),
+    (7, {"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "64"}, True),
+])
+def test_chunk_parallel_viterbi_with_segment_ratios(monkeypatch, N, env, big):
+    """Decode on a segmented table (_hmm.pyx:229-247: lt[j][j] * (r - 1) for r > 1 on every candidate but the
+    from-state-0 one, which gets lt[j][j] * r, quirk Q4) through the chunk-parallel exact Viterbi path: paths and
+    scores bit-exact against the oracle, and chunks really are jumped over."""
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    from oracle import oracle
+    for k in SPEC_ENV:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    model = synth.make_model(N, seed=11 + N)
+    lens = [1, 300, 5000, 60000, 150000] if env["TEHMM_SPEC_CHUNK"] != "1024" else [700, 90000, 400000]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = synth.sample_obs(model, int(offs[-1]), seed=N, missing=0.03)
+    ratios = _mixed_ratios(int(offs[-1]), seed=N + len(env), big=big)
+    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, 1.0, model.symbols_per_track)
+    hb = HipBatch(obs, offs, ratios)
+    for want_post in (False, True):             # Viterbi alone, then next to the posterior pipeline
+        res = hm.eval(hb, viterbi=True, posterior=want_post)
+        t = hb.timing()
+        assert t["count:viterbi_chunk_jumps"] > 0, t
+    p_o, vlp_o, flp_o, post_o = oracle.eval_batch(obs, offs, model.log_probs, model.log_startprob,
+                                                  model.log_transmat, 1.0, ratios, n_threads=4)
+    assert_array_equal(hb.paths(), p_o)
+    assert_array_equal(res["viterbi_logprob"], vlp_o)
+    assert_allclose(res["forward_logprob"], flp_o, rtol=RTOL)
+    assert_allclose(hb.posteriors(), post_o, rtol=RTOL, atol=1e-15)
+    hb.close()
+
+
+def test_segment_ratio_self_transition_zero_uses_sequential_path(monkeypatch):
+    """A state that cannot follow itself (lt[j][j] = -inf) makes the ratio products -inf / NaN: such models stay
+    on the sequential kernels, whose arithmetic is the reference's own."""
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    from oracle import oracle
+    for k in SPEC_ENV:
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("TEHMM_SPEC_CHUNK", "256")
+    monkeypatch.setenv("TEHMM_LANE_SUB", "64")
+    model = synth.make_model(12, seed=5)
+    lt = model.log_transmat.copy()
+    lt[3, 3] = -np.inf
+    lens = [4000, 30000]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = synth.sample_obs(model, int(offs[-1]), seed=1)
+    ratios = _mixed_ratios(int(offs[-1]), seed=3)
+    ratios[ratios < 1.0] = 1.0                    # (0 * -inf would be NaN in the reference too)
+    hm = HipModel(lt, model.log_startprob, model.log_probs, 1.0, model.symbols_per_track)
+    hb = HipBatch(obs, offs, ratios)
+    res = hm.eval(hb, viterbi=True, posterior=False)
+    assert "count:viterbi_chunk_jumps" not in hb.timing()
+    p_o, vlp_o, _, _ = oracle.eval_batch(obs, offs, model.log_probs, model.log_startprob, lt, 1.0, ratios,
+                                         want_post=False, n_threads=4)
+    assert_array_equal(hb.paths(), p_o)
+    assert_array_equal(res["viterbi_logprob"], vlp_o)
+    hb.close()
+
+
 def test_config3b_k32_vs_oracle():
     """BASELINE configs[2] variant 3b: the alyrata track-XML shape, K = 32 (15 multinomial + 14 gaussian /
     250 bins + 3 binary), several intervals incl. ragged ones: Viterbi bit-exact, posteriors 1e-6."""

@@ -1,5 +1,5 @@
 """Stage timings of the fused eval in isolation: posterior only, Viterbi only, both (bench workload).
-usage: python tools/stage_bench.py [Mb]"""
+usage: [STAGES=viterbi] [SINGLE=1] python tools/stage_bench.py [Mb]"""
 import os, sys, json
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,6 +13,8 @@ dev = torch.device("cuda", 0)
 model = synth.make_model(int(os.environ.get("STATES", bench.N_STATES)), synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=0)
 total = int(mb * 1e6)
 lens = synth.interval_lengths(total, 200_000, 2_000_000, seed=1000)
+if os.environ.get("SINGLE"):              # one interval of `Mb` (BASELINE configs[1] geometry)
+    lens = np.asarray([total], dtype=np.int64)
 offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
 obs = bench.gen_obs_torch(model, lens, seed=17, device=dev)
 torch.cuda.synchronize()
