@@ -45,12 +45,14 @@ def build(force=False, verbose=False, dev_nt=None):
     (fast to compile; every other N then fails with TEHMM_ERR_UNSUPPORTED-like silence -- never ship it)."""
     dev_nt = dev_nt or os.environ.get("TEHMM_DEV_NT")
     flags = "-DTEHMM_DEV_NT=%d" % int(dev_nt) if dev_nt else ""
+    extra = os.environ.get("TEHMM_EXTRA_FLAGS", "").split()      # diagnostics builds (e.g. -DTEHMM_CHAIN_PROF)
+    flags = " ".join(([flags] if flags else []) + extra)
     if not force and not needs_build(flags):
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
            "-std=c++17", "-Wall", "-Wno-unused-function", "-o", LIB] + SOURCES
-    if dev_nt:
-        cmd.insert(1, flags)
+    if flags:
+        cmd[1:1] = flags.split()
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     if os.path.exists(STAMP):

@@ -143,7 +143,8 @@ struct SpecWork {
   std::vector<int64_t> h_t0, h_first;
   DBuf<int> iv, e, ok, stats, ntie, ties;
   DBuf<int64_t> t0, first;
-  DBuf<double> gain, wmin, rows, tierows, scale, wstart, segmin, offend, clk;
+  DBuf<double> gain, wmin, rows, tierows, scale, wstart, segmin, offend, clk, racc, rmn;
+  DBuf<int64_t> rtarget, rsel;
   DBuf<int> clink;
 };
 
@@ -168,11 +169,11 @@ struct LaneWork {
   DBuf<float> B32;
   DBuf<VitChunks> d_vc;       // device copies of the argument tables of k_vit_lane
   DBuf<VitItems> d_vi;
-  DBuf<int> vbad, vntie, vties, wk_g, wk_e;
+  DBuf<int> vbad, vntie, vties, wk_g, wk_e, wk_items;
   // host staging of one evaluation: sources of asynchronous copies, alive until the call has
   // synchronised its streams
   std::vector<double> hs_gain, hs_cgain, hs_qt;
-  std::vector<int> hs_e, hs_wkg, hs_wke;
+  std::vector<int> hs_e, hs_wkg, hs_wke, hs_wki;
   VitChunks hs_vc;
   VitItems hs_vi;
 };
@@ -820,7 +821,8 @@ static int spec_prepare(tehmm_batch *b, const tehmm_model *m, int CS) {
   HIPCHK(sw.first.upload(sw.h_first.data(), sw.h_first.size()));
   HIPCHK(sw.e.alloc(nc));
   HIPCHK(sw.ok.alloc(nc));
-  HIPCHK(sw.stats.alloc(8));
+  HIPCHK(sw.stats.alloc(16));
+  HIPCHK(hipMemset(sw.stats.p, 0, 16 * sizeof(int)));
   HIPCHK(sw.scale.alloc(nc * (size_t)(CS / 32)));
   HIPCHK(sw.wstart.alloc(nc * (size_t)m->NP));
   HIPCHK(sw.gain.alloc(nc));
@@ -832,13 +834,20 @@ static int spec_prepare(tehmm_batch *b, const tehmm_model *m, int CS) {
   HIPCHK(sw.segmin.alloc(nc * (TEHMM_SPEC_MAXT + 1)));
   HIPCHK(sw.offend.alloc(nc));
   HIPCHK(sw.clk.alloc(nc));
+  HIPCHK(sw.racc.alloc(nc));
+  HIPCHK(sw.rmn.alloc(nc));
+  HIPCHK(sw.rtarget.alloc(nc));
+  HIPCHK(sw.rsel.alloc(nc));
   HIPCHK(sw.clink.alloc(nc));
   HIPCHK(hipMemset(sw.clink.p, 0, nc * sizeof(int)));
   return TEHMM_OK;
 }
 
 // Which binade each chunk lives in, from the plain-fp chunk gains of pass P0 (approximate prefix
-// sums are enough: a wrong or risky guess only sends that chunk to the sequential chain).
+// sums are enough: a wrong or risky guess only sends that chunk to the sequential chain -- the chain's
+// check demands every live value inside the chunk's binade and, from the recorded minima, up to the
+// landing position).  The margin (512 + 2e-5 |V|; float P0 sums are good to ~2e-6) only keeps chunks
+// that end within it of a binade boundary from being speculated in the wrong binade.
 static void spec_assign_binades(const tehmm_batch *b, const std::vector<double> &gain, std::vector<int> &e) {
   const SpecWork &sw = b->sw;
   e.assign((size_t)std::max(1, sw.n_chunks), TEHMM_SPEC_NONE);
@@ -850,7 +859,7 @@ static void spec_assign_binades(const tehmm_batch *b, const std::vector<double> 
       v = ve;
       const bool full = sw.h_t0[(size_t)c] + sw.CS <= b->h_len[i];
       if (c == sw.h_first[i] || !full || !(g == g) || !(g < 0.0)) continue;
-      static const double rel = std::getenv("TEHMM_SPEC_MARGIN") ? std::atof(std::getenv("TEHMM_SPEC_MARGIN")) : 5e-4;
+      static const double rel = std::getenv("TEHMM_SPEC_MARGIN") ? std::atof(std::getenv("TEHMM_SPEC_MARGIN")) : 2e-5;
       const double margin = 512.0 + rel * std::fabs(ve);
       const double lo = std::fabs(vs) - margin, hi = std::fabs(ve) + margin;
       if (!(lo > 0.0)) continue;
@@ -1095,14 +1104,14 @@ static void launch_vit_lane(tehmm_batch *b, const tehmm_model *m, const Interval
     hipLaunchKernelGGL((k_vit_lane<NT, true, true>), grid, dim3(256), 0, st, iv, lg, (const VitChunks *)lw.d_vc.p,
                        (const VitItems *)lw.d_vi.p, m->N, Wu,
                        (const int *)lw.wk_g.p, (const int *)lw.wk_e.p, n_work, (const double *)lw.qtabs.p, e0,
-                       (const double *)lw.B.p, b->tb.p, (const double *)b->ratios.p);
+                       (const double *)lw.B.p, b->tb.p, (const double *)b->ratios.p, (const int *)lw.wk_items.p);
     return;
   }
   if (quant) {
     hipLaunchKernelGGL((k_vit_lane<NT, true>), grid, dim3(256), 0, st, iv, lg, (const VitChunks *)lw.d_vc.p,
                        (const VitItems *)lw.d_vi.p, m->N, Wu,
                        (const int *)lw.wk_g.p, (const int *)lw.wk_e.p, n_work, (const double *)lw.qtabs.p, e0,
-                       (const double *)lw.B.p, b->tb.p, (const double *)nullptr);
+                       (const double *)lw.B.p, b->tb.p, (const double *)nullptr, (const int *)lw.wk_items.p);
   }
 }
 
@@ -1118,6 +1127,7 @@ static void launch_vit_stitch(tehmm_batch *b, const tehmm_model *m, const Interv
   else
     hipLaunchKernelGGL((k_vit_links<NT>), dim3((vc.n + 3) / 4), dim3(256), 0, st, iv, lane_geom(lw), vc,
                        lane_vit_items(lw), m->N);
+  hipLaunchKernelGGL(k_vit_runs, dim3(std::max(1, b->n)), dim3(64), 0, st, vc, b->n);
 }
 
 static LaneGeom lane_geom(const LaneWork &lw) {
@@ -1506,6 +1516,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     vc.e = sw.e.p; vc.gain = sw.gain.p; vc.ok = sw.ok.p; vc.wmin = sw.wmin.p; vc.rows = sw.rows.p;
     vc.ntie = sw.ntie.p; vc.ties = sw.ties.p; vc.tierows = sw.tierows.p; vc.segmin = sw.segmin.p;
     vc.offend = sw.offend.p; vc.clink = sw.clink.p; vc.clk = sw.clk.p;
+    vc.rtarget = sw.rtarget.p; vc.rsel = sw.rsel.p; vc.racc = sw.racc.p; vc.rmn = sw.rmn.p;
     if (glane) {
       if (!emis_gain) {
 #define CALL(NT_) launch_gain_lane<NT_>(b, m, iv, CS, WuV, st)
@@ -1663,20 +1674,40 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
         for (int c = 0; c < sw.n_chunks; ++c)
           if (he[(size_t)c] != TEHMM_SPEC_NONE && !eok[(size_t)(he[(size_t)c] - emin)]) he[(size_t)c] = TEHMM_SPEC_NONE;
         HIPCHK(lw.qtabs.fill_async(qt.data(), qt.size(), st));
+        // a group whose speculated items share one binade is one work unit; the items of the others (interval
+        // heads, binade crossings) are pooled per binade and dealt out 64 to a wave
+        std::vector<std::vector<int>> pool((size_t)(emax - emin + 1));
         for (int g = 0; g < lw.n_groups; ++g) {
-          int seen[8];
-          int ns = 0;
-          for (int ln = 0; ln < 64 && g * 64 + ln < lw.n_items; ++ln) {
+          int e1 = TEHMM_SPEC_NONE;
+          bool mixed = false;
+          const int nl = std::min(64, lw.n_items - g * 64);
+          for (int ln = 0; ln < nl; ++ln) {
             const size_t item = (size_t)g * 64 + ln;
-            const int id = lw.h_iv[item];
-            const int e = he[(size_t)(sw.h_first[id] + lw.h_t0[item] / CS)];
+            const int e = he[(size_t)(sw.h_first[lw.h_iv[item]] + lw.h_t0[item] / CS)];
             if (e == TEHMM_SPEC_NONE) continue;
-            bool dup = false;
-            for (int q = 0; q < ns; ++q) dup = dup || seen[q] == e;
-            if (!dup && ns < 8) { seen[ns++] = e; wk_g.push_back(g); wk_e.push_back(e); }
-            else if (!dup) he[(size_t)(sw.h_first[id] + lw.h_t0[item] / CS)] = TEHMM_SPEC_NONE;
+            if (e1 == TEHMM_SPEC_NONE) e1 = e;
+            else if (e != e1) mixed = true;
+          }
+          if (e1 == TEHMM_SPEC_NONE) continue;
+          if (!mixed) { wk_g.push_back(g); wk_e.push_back(e1); continue; }
+          for (int ln = 0; ln < nl; ++ln) {
+            const size_t item = (size_t)g * 64 + ln;
+            const int e = he[(size_t)(sw.h_first[lw.h_iv[item]] + lw.h_t0[item] / CS)];
+            if (e != TEHMM_SPEC_NONE) pool[(size_t)(e - emin)].push_back((int)item);
           }
         }
+        std::vector<int> &wki = lw.hs_wki;
+        wki.clear();
+        for (int e = emin; e <= emax; ++e) {
+          const std::vector<int> &pl = pool[(size_t)(e - emin)];
+          for (size_t i0 = 0; i0 < pl.size(); i0 += 64) {
+            const int slot = (int)(wki.size() / 64);
+            for (size_t i = 0; i < 64; ++i) wki.push_back(i0 + i < pl.size() ? pl[i0 + i] : -1);
+            wk_g.push_back(-(1 + slot));
+            wk_e.push_back(e);
+          }
+        }
+        if (!wki.empty()) HIPCHK(lw.wk_items.fill_async(wki.data(), wki.size(), st));
       }
       {
         // waves of one binade next to each other: they share one quantised table in the scalar cache
@@ -1843,6 +1874,15 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     // counters (not times): 64-position blocks the exact chain ran / chunks it could jump over
     int st[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpy(st, b->sw.stats.p, sizeof(st), hipMemcpyDeviceToHost));
+#ifdef TEHMM_CHAIN_PROF
+    {
+      int pr[4];
+      HIPCHK(hipMemcpy(pr, b->sw.stats.p + 8, sizeof(pr), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemset(b->sw.stats.p + 8, 0, sizeof(pr)));
+      std::fprintf(stderr, "[chain prof] summed over intervals, ms: prologue %.2f steps %.2f barrier %.2f\n", pr[0] * 1e-4,
+                   pr[1] * 1e-4, pr[2] * 1e-4);
+    }
+#endif
     if (std::getenv("TEHMM_SPEC_DEBUG")) {
       std::vector<int> he((size_t)b->sw.n_chunks), hok((size_t)b->sw.n_chunks);
       HIPCHK(hipMemcpy(he.data(), b->sw.e.p, he.size() * sizeof(int), hipMemcpyDeviceToHost));
@@ -1854,6 +1894,24 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       }
       std::fprintf(stderr, "[tehmm spec] chunks %d, speculated %d, usable %d, jumped %d, exact blocks %d\n",
                    b->sw.n_chunks, na, nok, st[1], st[0]);
+      if (vlane) {
+        // what ends the verified runs: ties inside chunks, chunks that do not link to their predecessor
+        std::vector<int> hnt(he.size()), hcl(he.size());
+        HIPCHK(hipMemcpy(hnt.data(), b->sw.ntie.p, hnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hcl.data(), b->sw.clink.p, hcl.size() * sizeof(int), hipMemcpyDeviceToHost));
+        long ties = 0, tchunks = 0, unlinked = 0, unl_samee = 0;
+        for (size_t i = 0; i < he.size(); ++i) {
+          if (he[i] == TEHMM_SPEC_NONE || !hok[i]) continue;
+          ties += hnt[i];
+          tchunks += hnt[i] > 0;
+          if (!hcl[i]) {
+            ++unlinked;
+            if (i > 0 && he[i - 1] == he[i] && hok[i - 1]) ++unl_samee;
+          }
+        }
+        std::fprintf(stderr, "[tehmm spec] ties %ld in %ld chunks, unlinked chunks %ld (%ld next to a usable chunk of the same binade)\n",
+                     ties, tchunks, unlinked, unl_samee);
+      }
     }
     b->tnames.push_back("count:viterbi_exact_blocks");
     b->tms.push_back((double)st[0]);

@@ -651,19 +651,28 @@ template <int NT, bool QUANT, bool RATIO = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TEHMM_P2_WAVES, TEHMM_P2_WAVES)))
 void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItems *vip, int N, int Wu, const int *wk_g,
                 const int *wk_e, int n_work, const double *__restrict__ tabs, int e0,
-                const double *__restrict__ B, uint8_t *tb, const double *__restrict__ ratios = nullptr) {
+                const double *__restrict__ B, uint8_t *tb, const double *__restrict__ ratios = nullptr,
+                const int *__restrict__ wk_items = nullptr) {
   const int lane = threadIdx.x & 63;
   const int wk = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wave-uniform
   if (wk >= n_work) return;
-  const int g = QUANT ? wk_g[wk] : wk;
+  // work unit: a whole group of 64 consecutive items (wk_g >= 0: all its chunks of binade e run), or -- groups
+  // that mix binades (interval heads, binade crossings) -- a list of up to 64 items of ONE binade collected
+  // over all such groups (wk_g = -(1 + slot), items wk_items[64 slot ..], -1 = empty lane)
+  const int gq = QUANT ? wk_g[wk] : wk;
   const int e = QUANT ? wk_e[wk] : 0;
   // the chunk / item tables are reached through pointers that are re-read where they are needed (rare
   // paths): as by-value arguments their 22 pointers stay in SGPRs across the unrolled step and spill
   auto VC = [&]() { const VitChunks *q = vcp; asm volatile("" : "+s"(q)); return *q; };
   auto VI = [&]() { const VitItems *q = vip; asm volatile("" : "+s"(q)); return *q; };
   const int L = lg.L, CS = vcp->CS;
-  const int64_t item = (int64_t)g * 64 + lane;
-  const bool valid = item < lg.n_items;
+  int64_t item = (int64_t)gq * 64 + lane;
+  bool valid = item < lg.n_items;
+  if (QUANT && gq < 0) {
+    const int li = wk_items[(int64_t)(-1 - gq) * 64 + lane];
+    valid = li >= 0;
+    item = valid ? li : 0;
+  }
   const int id = valid ? lg.item_iv[item] : 0;
   const int64_t t0 = valid ? lg.item_t0[item] : 0;
   const int64_t T = iv.len[id], p0 = iv.pos0[id];
@@ -702,10 +711,18 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItem
   // vector stays intact until the end of the step, which is when a rounding tie found on the way is
   // recorded.
   double bnx[4];
+#ifndef TEHMM_P2_PF
+#define TEHMM_P2_PF 2      // emission values are requested this many output groups ahead
+#endif
+  double bny[4];
   bool pending = false;
   auto prefetch = [&](const double *row, int og) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) bnx[q] = row[(int64_t)(4 * og + q) << 6];
+  };
+  auto prefetch2 = [&](const double *row, int og) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bny[q] = row[(int64_t)(4 * og + q) << 6];
   };
   auto step = [&](const double *bp, const double *bpn, int s, double rt) {
     const bool official = s >= 0;
@@ -757,8 +774,15 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItem
         // x = max_f W[f] + tab[f][o]   (tab scalar; QUANT: it carries the from-index in its low bits)
 #pragma unroll
         for (int q = 0; q < 4; ++q) bc[q] = bnx[q];
-        if (og + 1 < NT / 4) prefetch(bp, og + 1);
-        else prefetch(bpn, 0);
+        if (TEHMM_P2_PF == 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bnx[q] = bny[q];
+          if (og + 2 < NT / 4) prefetch2(bp, og + 2);
+          else prefetch2(bpn, og + 2 - NT / 4);
+        } else {
+          if (og + 1 < NT / 4) prefetch(bp, og + 1);
+          else prefetch(bpn, 0);
+        }
         x0 = W[0] + tc[0];
         if (RATIO) x0 += 64.0 * d0[0];
       } else {
@@ -890,7 +914,7 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItem
     }
   };
   auto vec_out = [&](double *dst) {
-    const int64_t po = (((int64_t)g * NT) << 6) + lane;
+    const int64_t po = (((item >> 6) * NT) << 6) + (item & 63);
 #pragma unroll
     for (int j = 0; j < NT; ++j) dst[po + ((int64_t)j << 6)] = QUANT ? W[j] * 0.015625 + base : W[j];
   };
@@ -912,7 +936,10 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItem
     const double *bp = B + (s < 0 ? lane_row(lg, NT, nb, L + s) : lane_row(lg, NT, item, s));
     const int sn = min(s + 1, L - 1);
     const double *bpn = B + (sn < 0 ? lane_row(lg, NT, nb, L + sn) : lane_row(lg, NT, item, sn));
-    if (s == -Wu) prefetch(bp, 0);
+    if (s == -Wu) {
+      prefetch(bp, 0);
+      if (TEHMM_P2_PF == 2) prefetch2(bp, 1);
+    }
     double rt = 1.0;
     if (RATIO) {
       // (positions t0 + s of the interval: the warm-up reads the previous item's; one step ahead)
@@ -1057,6 +1084,77 @@ __global__ __launch_bounds__(256) void k_vit_links(IntervalTab iv, LaneGeom lg, 
   if (lane == 0) {
     vc.clink[c] = link;
     vc.clk[c] = lk;
+  }
+}
+
+
+// Runs of linked chunks (after k_vit_links, one wave per interval): for every chunk, where a jump that
+// enters its first segment lands -- the chunk's first tie, else on through the linked chunks behind it to
+// their first tie or the end of the run -- with the frame offset and the lowest live value collected on the
+// way.  A suffix scan over the interval's chunks (tiles of 64 from the back) of the maps
+//   STOP(target, sel, mn)                    chunk with a tie, or the last of its run
+//   PASS(k, s): (target, sel, acc, mn) -> (target, sel, k + acc, min(s, k + mn))     k = clk of the next chunk
+// whose composition is associative and exact (every term is a multiple of the binade's grid unit).
+struct VitRunMap {
+  int stop;
+  int64_t target, sel;
+  double acc, mn;
+};
+__device__ __forceinline__ VitRunMap vit_run_compose(const VitRunMap &a, const VitRunMap &b) {   // a after b
+  if (a.stop) return a;
+  VitRunMap r;
+  r.stop = b.stop;
+  r.target = b.target;
+  r.sel = b.sel;
+  r.acc = a.acc + b.acc;
+  r.mn = fmin(a.mn, a.acc + b.mn);
+  return r;
+}
+__global__ __launch_bounds__(64) void k_vit_runs(VitChunks vc, int n_iv) {
+  const int lane = threadIdx.x;
+  const int id = blockIdx.x;
+  if (id >= n_iv) return;
+  const int64_t c0 = vc.first[id], c1 = vc.first[id + 1];
+  VitRunMap carry{0, 0, 0, 0.0, INFINITY};                 // identity (the interval's last chunk always stops)
+  for (int64_t hi = c1; hi > c0; hi -= 64) {
+    const int64_t c = hi - 64 + lane;                        // lanes ascending in chunk order; tile = [hi - 64, hi)
+    const bool in = c >= c0;
+    VitRunMap m{0, 0, 0, 0.0, INFINITY};
+    if (in) {
+      const double s0 = vc.segmin[c * (TEHMM_SPEC_MAXT + 1)];
+      const bool linked_next = c + 1 < c1 && vc.clink[c + 1] != 0;
+      if (vc.ntie[c] > 0) {
+        m = VitRunMap{1, vc.t0[c] + vc.ties[c * TEHMM_SPEC_MAXT], 2 * c, 0.0, s0};
+      } else if (linked_next) {
+        m = VitRunMap{0, 0, 0, vc.clk[c + 1], s0};
+      } else {
+        m = VitRunMap{1, vc.t0[c] + vc.CS, 2 * c + 1, 0.0, s0};
+      }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      VitRunMap o;
+      o.stop = __shfl_down(m.stop, d);
+      o.target = __shfl_down(m.target, d);
+      o.sel = __shfl_down(m.sel, d);
+      o.acc = __shfl_down(m.acc, d);
+      o.mn = __shfl_down(m.mn, d);
+      if (lane + d < 64) m = vit_run_compose(m, o);
+    }
+    m = vit_run_compose(m, carry);
+    if (in) {
+      vc.rtarget[c] = m.target;
+      vc.rsel[c] = m.sel;
+      vc.racc[c] = m.acc;
+      vc.rmn[c] = m.mn;
+    }
+    // carry = the map of the tile's first chunk (lane 0 is the lowest chunk index of the tile, or out of range
+    // in the interval's first tile, after which the loop ends)
+    carry.stop = __shfl(m.stop, 0);
+    carry.target = __shfl(m.target, 0);
+    carry.sel = __shfl(m.sel, 0);
+    carry.acc = __shfl(m.acc, 0);
+    carry.mn = __shfl(m.mn, 0);
   }
 }
 

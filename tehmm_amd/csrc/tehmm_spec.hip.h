@@ -36,7 +36,10 @@ namespace tehmm {
 
 #define TEHMM_SPEC_NONE (-2147483647 - 1)
 #ifndef TEHMM_SPEC_MIN_E
-#define TEHMM_SPEC_MIN_E 18          // speculate only where |V| >= 2^18 (room for the index bits)
+// speculate only where |V| >= 2^15: the quantised pass keeps 64 x (offset from the best state) + 6 index bits
+// exact, so a state may fall 2^(e-5) = 1024 behind inside a re-basing window at e = 15 (items that exceed it
+// are left to the exact chain), and a chunk of 1024 positions still fits inside two binades
+#define TEHMM_SPEC_MIN_E 15
 #endif
 
 struct VitChunks {
@@ -58,6 +61,12 @@ struct VitChunks {
   int *clink;             // lane passes: [chunk] 1 = the chunk's first segment continues the previous
                           //   chunk's last one (same binade, exact constant difference)
   double *clk;            // lane passes: [chunk] that constant: frame(previous) = frame(this) + clk
+  // k_vit_runs: where a verified jump that enters the chunk's FIRST segment ends -- its first tie, or on
+  // through the linked chunks behind it (a suffix scan, so that the chain does not walk the run itself)
+  int64_t *rtarget;       // [chunk] position the jump lands on
+  int64_t *rsel;          // [chunk] 2 * chunk' + (0: W row before that chunk's first tie, 1: its last row)
+  double *racc;           // [chunk] sum of clk over the chunks walked: frame(this) = frame(chunk') + racc
+  double *rmn;            // [chunk] lowest live W up to the landing position, in the chunk's frame
 };
 #define TEHMM_SPEC_MAXT 32
 #define TEHMM_VROW 16             // spacing of the recorded W rows
@@ -244,6 +253,7 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
   double *ltab = Vring + 2 * (CPB + 1) * VS;
   volatile int64_t *seqpos = (volatile int64_t *)(ltab + em.lds_rows * NT);
   volatile int *gen = (volatile int *)(seqpos + 4);
+  volatile int *blen = gen + 2;         // [4] positions the chain really ran in the block of iteration it & 3
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
   const int id = iv.order[blockIdx.x];
@@ -255,6 +265,7 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
     seqpos[0] = 0;
     seqpos[1] = seqpos[2] = seqpos[3] = T;
     *gen = 0;
+    blen[0] = blen[1] = blen[2] = blen[3] = 0;
   }
   const int jl = min(lane, NT - 1);
   const bool live = lane < N;
@@ -280,6 +291,12 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
     const int vslot = lane < NT ? lane : NT + 1;
     double vcur = -INFINITY;
     int n_jump = 0, n_block = 0;
+#ifdef TEHMM_CHAIN_PROF
+    unsigned long long prof[4] = {0, 0, 0, 0}, pt = __builtin_amdgcn_s_memrealtime();
+#define CPROF(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); prof[i] += n_ - pt; pt = n_; } while (0)
+#else
+#define CPROF(i)
+#endif
     for (int it = 0;; ++it) {
       const int64_t cur = seqpos[it & 3];
       const int64_t prev = it > 0 ? seqpos[(it - 1) & 3] : T;
@@ -316,21 +333,18 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
           if (SEGMIN) {
             smin = vc.segmin[c * (TEHMM_SPEC_MAXT + 1) + kseg];
             // the segment may run on through the following chunks (lane passes link them exactly when they
-            // share the binade): walk to its first tie or to the end of the linked run.  lkacc turns
-            // values of a later chunk's first-segment frame into the frame of the check row's segment.
-            int64_t cc = c;
-            const int64_t c_end = vc.first[id + 1];
-            while (target == vc.t0[cc] + vc.CS && cc + 1 < c_end && vc.clink[cc + 1] != 0) {
-              ++cc;
-              lkacc += vc.clk[cc];
-              smin = fmin(smin, vc.segmin[cc * (TEHMM_SPEC_MAXT + 1)] + lkacc);
-              if (vc.ntie[cc] > 0) {
-                target = vc.t0[cc] + vc.ties[cc * TEHMM_SPEC_MAXT];
-                trow = vc.tierows + (cc * TEHMM_SPEC_MAXT) * NT;
-              } else {
-                target = vc.t0[cc] + vc.CS;
-                trow = vc.rows + ((cc * (vc.CS / TEHMM_VROW)) + (vc.CS / TEHMM_VROW - 1)) * NT;
-              }
+            // share the binade) up to its first tie or the end of the linked run: k_vit_runs has walked that
+            // run.  lkacc turns values of the landing chunk's first-segment frame into the frame of the check
+            // row's segment.
+            if (target == ct0 + vc.CS && c + 1 < vc.first[id + 1] && vc.clink[c + 1] != 0) {
+              const int64_t cn = c + 1;
+              const double k1 = vc.clk[cn];
+              const int64_t sel = vc.rsel[cn];
+              lkacc = k1 + vc.racc[cn];
+              smin = fmin(smin, k1 + vc.rmn[cn]);
+              target = vc.rtarget[cn];
+              trow = (sel & 1) ? vc.rows + (((sel >> 1) * (vc.CS / TEHMM_VROW)) + (vc.CS / TEHMM_VROW - 1)) * NT
+                               : vc.tierows + ((sel >> 1) * TEHMM_SPEC_MAXT) * NT;
             }
           }
           if (pg >= CPB || g >= ct0 + vc.CS || target <= cur + CPB) spec = false;
@@ -344,6 +358,12 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
           if (lane == 0) { seqpos[(it + 1) & 3] = cur + np; *gen = it + 1; }
         }
         const double span = (spec && !SEGMIN) ? fabs(vc.gain[c]) * 1.01 + 256.0 : 0.0;
+        int nlen = np;
+#ifdef TEHMM_CHAIN_PROF
+        asm volatile("" :: "v"(wrow), "v"(wend), "v"(smin));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        CPROF(0);
         for (int p = 0; p < np; ++p) {
           const int64_t t = cur + p;
           const double b = br[p * RS + jl];
@@ -388,17 +408,26 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
             jump = __all(same && inb) && endok;
             delta = d0;
             if (lane == 0) { seqpos[(it + 1) & 3] = jump ? target : cur + np; *gen = it + 1; }
+            // verified: the rest of the block belongs to the speculative pass too (its pointer bytes stand)
+            if (jump) { nlen = p + 1; break; }
           }
         }
+        if (lane == 0) blen[it & 3] = nlen;
         if (jump) {
           vcur = wend + delta;          // V at position target - 1 (exact: both multiples of u)
           ++n_jump;
         }
+        CPROF(1);
       } else {
         if (lane == 0) { seqpos[(it + 1) & 3] = T; *gen = it + 1; }
       }
       __syncthreads();
+      CPROF(2);
     }
+#ifdef TEHMM_CHAIN_PROF
+    if (lane == 0 && stats)
+      for (int i = 0; i < 4; ++i) atomicAdd(&stats[8 + i], (int)(prof[i] / 10));      // 100 MHz ticks -> 0.1 us
+#endif
     double *scratch = Vring;
     if (lane < NT) scratch[lane] = vcur;
     __builtin_amdgcn_wave_barrier();
@@ -445,7 +474,7 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
       const int64_t prev = it > 0 ? seqpos[(it - 1) & 3] : T;
       if (cur >= T && prev >= T) break;
       if (it > 0 && prev < T) {
-        const int np = (int)min((int64_t)CPB, T - prev);
+        const int np = blen[(it - 1) & 3];
         const double *Vr = Vring + ((it - 1) & 1) * (CPB + 1) * VS;
         const double *br = bring + ((it - 1) % 3) * CPB * RS;
         const int pl = lane < np ? lane : 0;

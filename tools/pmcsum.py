@@ -3,7 +3,7 @@ import csv, collections, re, sys, glob
 pat = re.compile(sys.argv[2] if len(sys.argv) > 2 else "tehmm")
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
-for f in glob.glob(sys.argv[1] + "/*counter_collection.csv"):
+for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void tehmm::", "")
         if pat.search(k):
