@@ -318,6 +318,17 @@ def extras(args, model, hm, hb, obs, offs, lens, device, torch, mk_model):
         hbv.close()
         hmv.close()
         del ob
+    # (3b) state counts between the 36 the VALU lane kernels were first built for and the 64-lane limit
+    for ns in (50, 60):
+        mdl = synth.make_model(ns, synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=0)
+        ob = gen_obs_torch(mdl, lens[:sub], seed=33, device=device)
+        hmv = mk_model(mdl)
+        hbv = HipBatch(ob.data_ptr(), o3, device_ptrs=True, K=K)
+        d = time_eval(hmv, hbv, torch, viterbi=True, posterior=True)
+        ex["states_%d" % ns] = rate(n3, d, positions=n3, kernel_ms=hbv.timing())
+        hbv.close()
+        hmv.close()
+        del ob
     ob = gen_obs_torch(model, lens[:sub], seed=32, device=device)
     g = torch.Generator(device=device)
     g.manual_seed(5)

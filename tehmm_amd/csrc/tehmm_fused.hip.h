@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void k_fused_rowindex(IntervalTab iv, LaneGeom
 // Extended step e <-> position t0 - Wu + e; the pass covers e = 0 .. L + Wu - 1.
 // ------------------------------------------------------------------------------------------
 template <int NT, bool LOGDOM>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 36 ? 2 : 1, NT <= 36 ? 2 : 1)))
 void k_fused_fwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu,
                  const double *__restrict__ tab /* A, [NT][NT] row-major */, float *al32, double *chkf, double *pre,
                  double *end, double *slog32) {
@@ -435,7 +435,7 @@ void k_fused_fwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu
     FST(2);
     if (s >= 0 && run) {
       // alpha' row as floats: five float2 per lane (states kq + 4 (2p), kq + 4 (2p + 1)), 512 bytes per wave store
-      float2 *ar = (float2 *)al32 + al32_index(lg, item, s, kq) / 2;
+      float2 *ar = (float2 *)al32 + al32_index<NT>(lg, item, s, kq) / 2;
 #pragma unroll
       for (int p = 0; p < (KS + 1) / 2; ++p)
         ar[(int64_t)p * 64] = make_float2((float)v[2 * p], 2 * p + 1 < KS ? (float)v[2 * p + 1] : 0.f);
@@ -464,7 +464,7 @@ void k_fused_fwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu
 // Item-relative step s (L + Wu - 1 down to 0) <-> extended step s + Wu.
 // ------------------------------------------------------------------------------------------
 template <int NT, bool LOGDOM, bool EPS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 36 ? 2 : 1, NT <= 36 ? 2 : 1)))
 void k_fused_bwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu,
                  const double *__restrict__ tab /* A, [NT][NT] row-major */, const float *__restrict__ al32,
                  double *post, double *pre, double *end, double *chk) {
@@ -552,7 +552,7 @@ void k_fused_bwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu
     // alpha' row of this position (official range only; floats, five float2 per lane)
     float2 alp[(KS + 1) / 2];
     if (s < L) {
-      const float2 *ar = (const float2 *)al32 + al32_index(lg, item, s, kq) / 2;
+      const float2 *ar = (const float2 *)al32 + al32_index<NT>(lg, item, s, kq) / 2;
 #pragma unroll
       for (int p = 0; p < (KS + 1) / 2; ++p) alp[p] = run ? ar[(int64_t)p * 64] : make_float2(0.f, 0.f);
     }

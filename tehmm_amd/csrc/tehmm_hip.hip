@@ -407,7 +407,7 @@ int tehmm_update_counts_i32(int64_t T, int K, int N, int S, const int32_t *obs, 
 // ------------------------------------------------------------------------------------------
 // (Re)build the fused passes' emission tables from m->tab (model creation, M-step).
 static int build_ptab(tehmm_model *m) {
-  if (m->NP > 36) return TEHMM_OK;              // the lane passes are instantiated up to 36 padded states
+  if (m->NP > 64) return TEHMM_OK;              // the fused passes are instantiated up to 64 padded states
   const int KS = m->NP / 4, KSP = ((KS + 1) + 1) & ~1, ROW_D = 4 * KSP, ROW_L = ROW_D + 2, K = m->K;
   m->KSP = KSP;
   m->ptab_log = m->normalize != 1.0;
@@ -975,7 +975,7 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
   const size_t rows = (size_t)std::max(1, lw.n_groups) * L * 64;        // item-interleaved positions
   const size_t vecs = (size_t)std::max(1, lw.n_groups) * 64 * m->NP;
   if (want_fb && !lw.pre_f.p) {
-    if (fused_fb) HIPCHK(lw.AL32.alloc((size_t)std::max(1, lw.n_groups) * L * 2560));
+    if (fused_fb) HIPCHK(lw.AL32.alloc((size_t)std::max(1, lw.n_groups) * L * 512 * al32_pairs(m->NP)));
     else HIPCHK(lw.AL.alloc(rows * m->NP));
     HIPCHK(lw.pre_f.alloc(vecs));
     HIPCHK(lw.end_f.alloc(vecs));
@@ -996,7 +996,7 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
     HIPCHK(lw.chk.alloc((size_t)std::max(1, lw.n_groups) * 64 * (size_t)(L / 64) * m->NP));
     HIPCHK(lw.chkf.alloc((size_t)std::max(1, lw.n_groups) * 64 * (size_t)(L / 64) * m->NP));
   }
-  if (want_fb && fused_fb && !lw.AL32.p) HIPCHK(lw.AL32.alloc((size_t)std::max(1, lw.n_groups) * L * 2560));
+  if (want_fb && fused_fb && !lw.AL32.p) HIPCHK(lw.AL32.alloc((size_t)std::max(1, lw.n_groups) * L * 512 * al32_pairs(m->NP)));
   if (want_fb && !fused_fb && !lw.AL.p) HIPCHK(lw.AL.alloc(rows * m->NP));
   if (want_fb && !fused_fb && !lw.BH.p) {
     HIPCHK(lw.BE.alloc(rows * m->NP));
@@ -1431,7 +1431,10 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   LaneWork &lw = b->lw;
   const EmisTab emg = without_lds_tables(em);
   const int eV = 0, eP = 5;
-  int LS = ((vspec || fspec) && m->NP <= 36) ? lane_sub_size(CS, b->total) : 0;   // 4 * NP VGPRs of state
+  // lane = item geometry: the VALU lane passes (exact Viterbi, P0) hold 4 * NP VGPRs of state and stop at 36
+  // padded states; the fused matrix-core forward / backward passes go up to 64
+  const bool lane_vit_ok = m->NP <= 64;
+  int LS = ((vspec && lane_vit_ok) || fspec) ? lane_sub_size(CS, b->total) : 0;
   // The lane = item Viterbi passes (TEHMM_LANE_VIT, default on) additionally need the fp64 log rows.
   const char *lvs = std::getenv("TEHMM_LANE_VIT");
   bool want_vlane = !(lvs && std::atoi(lvs) == 0);
@@ -1462,11 +1465,11 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     vspec = false;                                    // no lane passes for this call: sequential Viterbi with ratios
     if (!fspec) LS = 0;
   }
-  const bool vlane = vspec && LS > 0 && want_vlane, flane = fspec && LS > 0;
+  const bool vlane = vspec && LS > 0 && want_vlane && lane_vit_ok, flane = fspec && LS > 0;
   // P0 (binade placement) as a packed-float lane pass over float emission rows; TEHMM_LANE_P0=0 keeps
   // the fp64 lane = state pass
   const char *lp0 = std::getenv("TEHMM_LANE_P0");
-  const bool glane = vspec && LS > 0 && (vlane || !(lp0 && std::atoi(lp0) == 0));
+  const bool glane = vspec && LS > 0 && lane_vit_ok && (vlane || !(lp0 && std::atoi(lp0) == 0));
   const char *wus = std::getenv("TEHMM_LANE_WARMUP");
   const int WuF = std::min(LS, std::max(1, wus ? std::atoi(wus) : 64));       // forward / backward warm-up
   const char *wvs = std::getenv("TEHMM_LANE_WARMUP_VIT");

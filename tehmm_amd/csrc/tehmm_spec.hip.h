@@ -566,11 +566,15 @@ __device__ __forceinline__ int64_t lane_row(const LaneGeom &lg, int NT, int64_t 
 // Fused passes (tehmm_fused.hip.h): the alpha' rows are kept in FLOAT (a posterior only needs their direction
 // to 1e-6) in a layout where the nine states of a matrix-core lane sit in five float2:
 //   element (item, t, state)  ->  [group][t][tile in group][state pair p = (state >> 2) >> 1][state & 3][item & 15][(state >> 2) & 1]
-// i.e. one 512-byte row per wave load / store; 2560 floats per (group, position).
+// i.e. one 512-byte row per wave load / store; 512 * P floats per (group, position), P = al32_pairs(NT)
+// float2 per lane (5 at 36 states: 2560 floats).
+__host__ __device__ constexpr int al32_pairs(int NT) { return (NT / 4 + 1) / 2; }
+template <int NT>
 __device__ __forceinline__ int64_t al32_index(const LaneGeom &lg, int64_t item, int64_t trel, int state) {
+  constexpr int P = al32_pairs(NT);
   const int64_t gt = (item >> 6) * lg.L + trel;
   const int tg = (int)((item >> 4) & 3), s = state >> 2;
-  return ((((gt * 4 + tg) * 5 + (s >> 1)) * 4 + (state & 3)) * 16 + (item & 15)) * 2 + (s & 1);
+  return ((((gt * 4 + tg) * P + (s >> 1)) * 4 + (state & 3)) * 16 + (item & 15)) * 2 + (s & 1);
 }
 
 // Hilbert projective distance (as max/min ratio - 1) between two non-negative vectors over the live
@@ -820,7 +824,7 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
             if (es && lane == 0) es[t] = e;
           }
           if (FUSED) {
-            if (live) al32[al32_index(lg, ifirst + t / lg.L, t % lg.L, jl)] = (float)v;
+            if (live) al32[al32_index<NT>(lg, ifirst + t / lg.L, t % lg.L, jl)] = (float)v;
           } else if (live) {
             brow[p * rstride] = v;
           }
@@ -865,7 +869,7 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
         double *po = post + (iv.out0[id] + lo) * N;
         for (int p = 0; p < np; ++p) {
           const int64_t tp = lo + p;
-          const double a = live ? (double)al32[al32_index(lg, ifirst + tp / lg.L, tp % lg.L, jl)] : 0.0;
+          const double a = live ? (double)al32[al32_index<NT>(lg, ifirst + tp / lg.L, tp % lg.L, jl)] : 0.0;
           const double g = a * (live ? br[p * RS + lane] : 0.0);
           const double tot = wave_sum_f64(g);
           if (live) po[(int64_t)p * N + lane] = (g / tot + eps) * inv_epsden;
