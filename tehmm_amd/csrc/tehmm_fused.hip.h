@@ -56,6 +56,9 @@ struct FusedGeom {
 //     waits complete in issue order: a wait for a fresh 8-byte read 12 KB away from its neighbour's, behind the
 //     previous step's stores, cost ~2 000 cycles three times per step in the version that read them directly).
 //   * ptab / the LDS copy: rows [4][KSP] as described above.
+#ifndef TEHMM_FUSED_2W
+#define TEHMM_FUSED_2W 36        // two waves per SIMD (256 registers each) up to this many padded states, one above
+#endif
 #define TEHMM_FUSED_BLKW 24      // index words per (item, block): SB = 24 / FKW steps per block
 
 struct FusedTab {
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(256) void k_fused_rowindex(IntervalTab iv, LaneGeom
 // Extended step e <-> position t0 - Wu + e; the pass covers e = 0 .. L + Wu - 1.
 // ------------------------------------------------------------------------------------------
 template <int NT, bool LOGDOM>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 36 ? 2 : 1, NT <= 36 ? 2 : 1)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= TEHMM_FUSED_2W ? 2 : 1, NT <= TEHMM_FUSED_2W ? 2 : 1)))
 void k_fused_fwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu,
                  const double *__restrict__ tab /* A, [NT][NT] row-major */, float *al32, double *chkf, double *pre,
                  double *end, double *slog32) {
@@ -464,7 +467,7 @@ void k_fused_fwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu
 // Item-relative step s (L + Wu - 1 down to 0) <-> extended step s + Wu.
 // ------------------------------------------------------------------------------------------
 template <int NT, bool LOGDOM, bool EPS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 36 ? 2 : 1, NT <= 36 ? 2 : 1)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= TEHMM_FUSED_2W ? 2 : 1, NT <= TEHMM_FUSED_2W ? 2 : 1)))
 void k_fused_bwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu,
                  const double *__restrict__ tab /* A, [NT][NT] row-major */, const float *__restrict__ al32,
                  double *post, double *pre, double *end, double *chk) {

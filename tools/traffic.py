@@ -6,7 +6,7 @@ are in KB.  Only the LAST dispatch of every kernel is used (the timed step; earl
 import csv, glob, json, re, sys, collections
 
 STAGE = [("k_emis_gain_lane", "emission_rows"), ("k_emis_lane", "emission_rows"), ("k_vit_gain_lane", "viterbi_speculate"),
-         ("k_vit_lane", "viterbi_speculate"), ("k_vit_stitch", "viterbi_speculate"), ("k_vit_links", "viterbi_speculate"),
+         ("k_vit_lane", "viterbi_speculate"), ("k_vit_stitch", "viterbi_speculate"), ("k_vit_links", "viterbi_speculate"), ("k_vit_runs", "viterbi_speculate"),
          ("k_vit_spec", "viterbi_speculate"), ("k_vit_fix", "viterbi"), ("k_vit_coop", "viterbi"), ("k_tb_", "traceback"),
          ("k_fused_fwd", "forward_pass"), ("k_fb_fix<36, 0", "forward_pass"), ("k_fused_bwd", "backward_posterior_pass"),
          ("k_fb_fix<36, 1", "backward_chain"), ("k_fb_itemlinks", "links"), ("k_fb_stitch", "links"), ("k_fb_runs", "links"),
