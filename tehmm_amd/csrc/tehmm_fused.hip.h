@@ -67,7 +67,8 @@ struct FusedTab {
   const double *ptab_lds;   // [lds_rows][ROW_D_LDS] the LDS-staged rows
   int FKW;                  // index words per position: ceil(K / 4) rounded up to a divisor of 24
   int SB, NB;               // steps per block, blocks per item (extended range)
-  int K, n_glb;             // tracks; the first n_glb of the processing order come from ptab
+  int K, n_glb;             // entries of an index record (tracks + identity padding, see EmisStream); the first
+                            // n_glb (>= EmisStream::NGS) come from ptab, then >= NSLOT from the LDS copy
   int lds_rows;
   double normalize;         // LOGDOM only
 };
@@ -175,16 +176,20 @@ __device__ __forceinline__ unsigned long long lds_read_u64(unsigned addr) {
 //   begin(e) ; slot(0) .. slot(NSLOT - 1) ; finish(q, ms)
 // Linear form: q = product of the track rows, ms = sum of their scale slots.  LOGDOM: q = exp(normalize *
 // sum - rowmax), ms = rowmax.  A row no state can emit comes out as all zeros (the callers turn it into NaN).
-// The schedule is FIXED at compile time (slot indices are constants of the unrolled loops; a run-time state
-// machine cost ~100 scalar instructions per slot): slot k folds the LDS track whose rows slot k - 1 requested,
-// requests the rows of LDS track k and reads the index word of track k + 1; the first global-table (L2) track
-// is requested in begin() and folded in slot GF, the second requested there and folded in finish().  Whatever
-// does not fit the slots (more than NSLOT LDS tracks, more than two global ones) is done in finish(), one
-// track after the other.
+// The schedule is FIXED at compile time AND free of branches: the host pads the track list of the index records
+// with identity rows (all ones; log: zeros) to NGS tracks served from the global table followed by NSLOT
+// LDS-staged ones, so every slot does the same thing whatever the model (a run-time state machine cost ~100
+// scalar instructions per slot; per-slot tests of the track counts cost ~35 scalar branches per step, each a
+// refetch through the instruction cache the kernel is bound by).  Slot k folds the LDS track whose rows slot
+// k - 1 requested, requests the rows of LDS track k and reads the index word of track k + 1; the first
+// global-table (L2) track is requested in begin() and folded in slot GF, the second requested there and folded
+// in finish().  Whatever does not fit (more than NSLOT LDS tracks, more than NGS global ones) is done in
+// finish(), one track after the other.
 template <int NT, bool LOGDOM>
 struct EmisStream {
   using G = FusedGeom<NT>;
   static constexpr int NSLOT = G::KS;
+  static constexpr int NGS = NSLOT > 1 ? 2 : 1;  // global tracks of the fixed schedule (FusedTab::n_glb >= NGS)
   static constexpr int GF = NSLOT >= 8 ? 4 : NSLOT / 2;
   const FusedTab &ft;
   const double *lds;
@@ -196,12 +201,9 @@ struct EmisStream {
   double xa[G::KSP];                             // global-table (L2) track in flight
   double xc[G::KSP];                             // LDS track in flight (requested in one slot, folded in the next)
   unsigned long long wcur = 0;                   // index word of the next LDS track
-  int nl;                                        // LDS tracks handled in slots (the rest in finish)
 
   __device__ __forceinline__ EmisStream(const FusedTab &ft_, const double *lds_, IndexWindow &win_, int kq_)
-      : ft(ft_), lds(lds_), win(win_), kq(kq_) {
-    nl = min(ft.K - ft.n_glb, NSLOT);
-  }
+      : ft(ft_), lds(lds_), win(win_), kq(kq_) {}
   static __device__ __forceinline__ int entry(unsigned long long w, int i) { return (int)((w >> (16 * (i & 3))) & 0xffffull); }
   __device__ __forceinline__ unsigned long long word(int w) const { return lds_read_u64(wbase + (unsigned)w * 128u); }
   __device__ __forceinline__ void fold(const double (&x)[G::KSP]) {
@@ -218,27 +220,23 @@ struct EmisStream {
 #pragma unroll
     for (int s = 0; s < G::KS; ++s) q[s] = LOGDOM ? 0.0 : 1.0;
     sc = 0.0;
-    if (ft.n_glb > 0) glb_request(0);
-    if (nl > 0) wcur = word(ft.n_glb >> 2);
+    glb_request(0);
+    wcur = word(ft.n_glb >> 2);
   }
   __device__ __forceinline__ void slot(int k) {
     const int il = ft.n_glb + k;                                // this slot's LDS track
-    if (k > 0 && k <= nl) fold(xc);                             // requested by the previous slot
+    if (k > 0) fold(xc);                                        // requested by the previous slot
     if (k == GF && NSLOT > 1) {
-      if (ft.n_glb > 0) fold(xa);
-      if (ft.n_glb > 1) glb_request(1);
+      fold(xa);
+      glb_request(1);
     }
-    if (k < nl) fused_load_lds<NT>(lds, entry(wcur, il), kq, xc);
-    if (k + 1 < nl) wcur = word((il + 1) >> 2);
+    fused_load_lds<NT>(lds, entry(wcur, il), kq, xc);
+    if (k + 1 < NSLOT) wcur = word((il + 1) >> 2);
   }
   __device__ __forceinline__ void finish(int N, double (&qo)[G::KS], double &ms) {
-    if (nl == NSLOT) fold(xc);                                  // the last slot's track
-    if (NSLOT > 1) {
-      if (ft.n_glb > 1) fold(xa);
-    } else if (ft.n_glb > 0) {
-      fold(xa);
-    }
-    for (int i = NSLOT > 1 ? 2 : 1; i < ft.n_glb; ++i) {        // further global tracks, one after the other
+    fold(xc);                                                   // the last slot's track
+    fold(xa);                                                   // the last global track of the schedule
+    for (int i = NGS; i < ft.n_glb; ++i) {                      // further global tracks, one after the other
       glb_request(i);
       fold(xa);
     }

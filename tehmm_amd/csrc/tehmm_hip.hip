@@ -496,7 +496,7 @@ int tehmm_model_create(int N, int K, int S, const double *lt, const double *pi,
       used += m->rowcnt[k];
     }
     m->lds_zero = used;                  // one row of zeros behind the staged rows
-    m->lds_rows = used > 0 ? used + 1 : 0;
+    m->lds_rows = used + 1;              // (always at least the zero row: the fused passes pad with it)
   }
   std::vector<double> hltab((size_t)std::max(1, m->lds_rows) * NP, 0.0);
   for (int k = 0; k < K; ++k)
@@ -1256,27 +1256,31 @@ static void launch_fused_fb(tehmm_batch *b, const tehmm_model *m, const Interval
   fo.K = m->K;
   fo.KP = b->KP;
   fo.Wu = Wu;
+  fo.zero_glb = m->R;
+  fo.zero_lds = m->lds_zero;
+  // the fixed schedule of EmisStream: at least NGS tracks from the global table, then at least NSLOT from LDS;
+  // the padding entries (cnt = 0) always read the identity row
+  {
+    constexpr int NSLOT = NT / 4, NGS = NSLOT > 1 ? 2 : 1;
+    int slot = 0;
+    auto pad = [&]() { fo.order[slot] = 0; fo.base[slot] = 0; fo.cnt[slot] = 0; ++slot; };
+    for (int k = 0; k < m->K; ++k)
+      if (m->ldsbase[k] < 0) { fo.order[slot] = (unsigned char)k; fo.base[slot] = m->rowbase[k]; fo.cnt[slot] = m->rowcnt[k]; ++slot; }
+    while (slot < NGS) pad();
+    fo.n_glb = slot;
+    for (int k = 0; k < m->K; ++k)
+      if (m->ldsbase[k] >= 0) { fo.order[slot] = (unsigned char)k; fo.base[slot] = m->ldsbase[k]; fo.cnt[slot] = m->rowcnt[k]; ++slot; }
+    while (slot - fo.n_glb < NSLOT) pad();
+    fo.K = slot;
+  }
   {
     static const int ok[] = {1, 2, 3, 4, 6, 8, 12, 24};          // divisors of TEHMM_FUSED_BLKW
-    int need = (m->K + 3) / 4;
+    int need = (fo.K + 3) / 4;
     fo.FKW = 24;
     for (int d : ok) if (d >= need) { fo.FKW = d; break; }
   }
   fo.SB = TEHMM_FUSED_BLKW / fo.FKW;
   fo.NB = (lw.L + 2 * Wu + fo.SB - 1) / fo.SB;
-  fo.zero_glb = m->R;
-  fo.zero_lds = m->lds_zero;
-  int slot = 0;
-  for (int pass = 0; pass < 2; ++pass)
-    for (int k = 0; k < m->K; ++k) {
-      const bool in_lds = m->ldsbase[k] >= 0;
-      if ((pass == 0) == in_lds) continue;
-      fo.order[slot] = (unsigned char)k;
-      fo.base[slot] = in_lds ? m->ldsbase[k] : m->rowbase[k];
-      fo.cnt[slot] = m->rowcnt[k];
-      ++slot;
-      if (pass == 0) fo.n_glb = slot;
-    }
   if (!lw.rix.p || lw.rix_model != m->uid || lw.rix_L != lw.L || lw.rix_Wu != Wu) {
     const size_t words = (size_t)lw.n_groups * 4 * fo.NB * TEHMM_FUSED_BLKW * 16;
     (void)lw.rix.ensure(words + 16);
@@ -1293,7 +1297,7 @@ static void launch_fused_fb(tehmm_batch *b, const tehmm_model *m, const Interval
   ft.FKW = fo.FKW;
   ft.SB = fo.SB;
   ft.NB = fo.NB;
-  ft.K = m->K;
+  ft.K = fo.K;
   ft.n_glb = fo.n_glb;
   ft.lds_rows = m->lds_rows;
   ft.normalize = m->normalize;
@@ -1441,7 +1445,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   // TEHMM_FUSED=0 selects the round-1 posterior pipeline (emission rows, alpha' and beta' through HBM,
   // separate combine); default: the fused passes of tehmm_fused.hip.h
   const char *fus = std::getenv("TEHMM_FUSED");
-  const bool fused_fb = !(fus && std::atoi(fus) == 0) && m->ptab.p != nullptr;
+  const bool fused_fb = !(fus && std::atoi(fus) == 0) && m->ptab.p != nullptr && m->K <= 78;   // (96 record entries incl. padding)
   if (LS > 0 && !b->lw.AL.p && !b->lw.AL32.p && !b->lw.B.p && !b->lw.B32.p) {
     // the item-interleaved buffers (8 * NP bytes per position each: alpha' -- plus, without the fused
     // passes, beta' and the linear emission rows --, the fp64 log rows of the exact Viterbi pass; 4 * NP
