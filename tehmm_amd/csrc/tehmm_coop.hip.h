@@ -628,26 +628,70 @@ __global__ __launch_bounds__(256) void k_combine(int64_t rows, int N, double *al
 // scalar operands.  Small tracks' histograms are privatised in LDS, the others use fp64 global
 // atomics.  C, D, start, the histograms are summed into global accumulators with atomics.
 // ------------------------------------------------------------------------------------------
+// sum over the 64 lanes, every lane gets it, without LDS: xor-butterfly inside the 16-lane rows by DPP on the two
+// halves of the double (quad_perm, row_half_mirror, row_mirror), then the four rows by permlane swaps (item_sum4)
 __device__ __forceinline__ double wave_sum_f64_all(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+#define TEHMM_DPP_ADD(CTRL)                                                                                  \
+  do {                                                                                                       \
+    const int lo_ = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);                       \
+    const int hi_ = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);                       \
+    v += __hiloint2double(hi_, lo_);                                                                         \
+  } while (0)
+  TEHMM_DPP_ADD(0xB1);     // quad_perm [1,0,3,2]
+  TEHMM_DPP_ADD(0x4E);     // quad_perm [2,3,0,1]
+  TEHMM_DPP_ADD(0x141);    // row_half_mirror
+  TEHMM_DPP_ADD(0x140);    // row_mirror
+#undef TEHMM_DPP_ADD
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  const double t1 = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+  const unsigned lo1 = __double2loint(t1), hi1 = __double2hiint(t1);
+  const auto c = __builtin_amdgcn_permlane16_swap(lo1, lo1, false, false);
+  const auto d = __builtin_amdgcn_permlane16_swap(hi1, hi1, false, false);
+  return __hiloint2double((int)d[0], (int)c[0]) + __hiloint2double((int)d[1], (int)c[1]);
 }
+// C[F] += V[F] * wz for F = 0..NT-1, the broadcast of V[F] folded into the FMA (r = rep_rows(V))
+template <int F, int NT>
+struct BcastOuter {
+  static __device__ __forceinline__ void run(const double (&r)[(NT + 15) / 16], double wz, double (&C)[NT]) {
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(C[F])
+                 : "v"(r[F >> 4]), "v"(wz), "n"(F & 15));
+    BcastOuter<F + 1, NT>::run(r, wz, C);
+  }
+};
+template <int NT>
+struct BcastOuter<NT, NT> {
+  static __device__ __forceinline__ void run(const double (&)[(NT + 15) / 16], double, double (&)[NT]) {}
+};
 
+// One wave per chunk of CH positions, lane = state j, C[i][lane] in registers; a_{t-1}[i] reaches the FMA as a DPP
+// row broadcast of the previous position's register (the first version read it back from memory: 36 dependent
+// uniform loads per position, 8.6 us per position and wave).  The rows of position t + 1 are requested before
+// position t is worked on.  Small tracks' histograms are privatised in LDS, the others use fp64 global atomics.
+// C, D, start, the histograms are summed into global accumulators with atomics.
 template <int NT, bool RATIO>
 __global__ __launch_bounds__(256) void k_estep_accum(IntervalTab iv, EmisTab em, int N, int chunk_len,
                                                      const int *chunk_iv, const int64_t *chunk_t0,
-                                                     int n_chunks, const double *alpha,
-                                                     const double *beta, const double *wrows,
-                                                     const int *escale, double *gC, double *gD,
+                                                     int n_chunks, const double *__restrict__ alpha,
+                                                     const double *__restrict__ beta, const double *__restrict__ wrows,
+                                                     const int *__restrict__ escale, double *gC, double *gD,
                                                      double *gstart, double *gstat) {
   extern __shared__ double sm[];
   double *lstat = sm;                       // [lds_rows][NT] privatised histogram of the small tracks
+  int *tinfo = (int *)(sm + (size_t)em.lds_rows * NT);     // [3][K]: ldsbase, rowcnt, rowbase (LDS: no per-use scalar loads)
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < em.lds_rows * NT; i += 256) lstat[i] = 0.0;
+  for (int k = threadIdx.x; k < em.K; k += 256) {
+    tinfo[k] = em.ldsbase[k];
+    tinfo[em.K + k] = em.rowcnt[k];
+    tinfo[2 * em.K + k] = em.rowbase[k];
+  }
   __syncthreads();
   const bool live = lane < N;
+  const int jl = min(lane, N - 1);
   const int c = blockIdx.x * 4 + w;
   if (c < n_chunks) {
     const int id = chunk_iv[c];
@@ -656,42 +700,73 @@ __global__ __launch_bounds__(256) void k_estep_accum(IntervalTab iv, EmisTab em,
     const int64_t r0 = iv.out0[id];
     const int64_t tlo = chunk_t0[c];
     const int64_t thi = min(T, tlo + chunk_len);
+    const int K = em.K, KPW = em.KPW;
+    // track k's table info in lane k (read back with v_readlane: no memory access in the track loop); tracks
+    // beyond 64 use the LDS copy
+    const int ti_lb = lane < K ? tinfo[lane] : -1, ti_cnt = lane < K ? tinfo[K + lane] : 0,
+              ti_rb = lane < K ? tinfo[2 * K + lane] : 0;
     double C[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) C[i] = 0.0;
     double D = 0.0;
-    for (int64_t t = tlo; t < thi; ++t) {
+    double aprev = (tlo > 0 && live) ? alpha[(r0 + tlo - 1) * N + lane] : 0.0;
+    // the rows of the position being worked on (requested one iteration ahead)
+    double a_n = 0.0, b_n = 0.0, w_n = 0.0, r_n = 1.0;
+    int e_n = 0;
+    uint32_t o_n[8];                          // observation words of the first 32 tracks (more: re-read below)
+    auto request = [&](int64_t t) {
       const int64_t row = r0 + t;
-      const double a = live ? alpha[row * N + lane] : 0.0;
-      const double b = live ? beta[row * N + lane] : 0.0;
+      a_n = alpha[row * N + jl];
+      b_n = beta[row * N + jl];
+      w_n = wrows[row * N + jl];
+      e_n = escale[row];
+      if (RATIO) r_n = em.ratios[p0 + t];
+      const uint32_t *orow = em.obs32 + (p0 + t) * KPW;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) o_n[d] = d < KPW ? orow[d] : 0u;
+    };
+    if (tlo < thi) request(tlo);
+    for (int64_t t = tlo; t < thi; ++t) {
+      const double a = live ? a_n : 0.0, b = live ? b_n : 0.0, wv = live ? w_n : 0.0, r = r_n;
+      const int es = e_n;
+      uint32_t ow[8];
+#pragma unroll
+      for (int d = 0; d < 8; ++d) ow[d] = o_n[d];
+      if (t + 1 < thi) request(t + 1);
       const double g = a * b;
       const double G = wave_sum_f64_all(g);
       const double invG = 1.0 / G;
-      double gam = g * invG;
-      double r = 1.0;
-      if (RATIO) r = em.ratios[p0 + t];
+      const double gam = g * invG;
       if (t == 0 && live) atomicAdd(&gstart[lane], gam);
       // ---- transition statistics for the pair (t-1, t)
       if (t > 0) {
-        const double wv = live ? wrows[row * N + lane] : 0.0;
-        const double wz = wv * ldexp(invG, -escale[row]);
-        const double *ap = alpha + (row - 1) * N;          // a_{t-1}[*]: wave-uniform, scalar loads
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-          if (i < N) C[i] = fma(ap[i], wz, C[i]);
+        const double wz = wv * ldexp(invG, -es);
+        double rr[(NT + 15) / 16];
+        rep_rows<NT>(aprev, rr);
+        asm volatile("s_nop 1" ::: "memory");                 // VALU write -> DPP read wait states
+        BcastOuter<0, NT>::run(rr, wz, C);
         if (RATIO && r > 1.) D += (r - 1.) * gam;
       }
+      aprev = a;
       // ---- emission statistics
       const double gr = RATIO ? gam * r : gam;
-      const uint32_t *orow = em.obs32 + (p0 + t) * em.KPW;
-      for (int k = 0; k < em.K; ++k) {
-        const int sym = (int)((orow[k >> 2] >> ((k & 3) * 8)) & 0xffu);
-        const int lb = em.ldsbase[k];
+      for (int k = 0; k < K; ++k) {
+        uint32_t word = ow[0];
+#pragma unroll
+        for (int d = 1; d < 8; ++d) word = (k >> 2) == d ? ow[d] : word;
+        if ((k >> 2) >= 8) word = em.obs32[(p0 + t) * KPW + (k >> 2)];
+        const int sym = (int)((word >> ((k & 3) * 8)) & 0xffu);
+        const int lb = k < 64 ? __builtin_amdgcn_readlane(ti_lb, k) : tinfo[k];
+        const int cnt = k < 64 ? __builtin_amdgcn_readlane(ti_cnt, k) : tinfo[K + k];
         // (a symbol beyond the track's last one lands in the reference's padding cells, which
         //  emission.maximize never reads: not booked here)
-        if (live && sym < em.rowcnt[k]) {
-          if (lb >= 0) atomicAdd(&lstat[(lb + sym) * NT + lane], gr);
-          else atomicAdd(&gstat[(int64_t)(em.rowbase[k] + sym) * NT + lane], gr);
+        if (live && sym < cnt) {
+          if (lb >= 0) {
+            atomicAdd(&lstat[(lb + sym) * NT + lane], gr);
+          } else {
+            const int rb = k < 64 ? __builtin_amdgcn_readlane(ti_rb, k) : tinfo[2 * K + k];
+            atomicAdd(&gstat[(int64_t)(rb + sym) * NT + lane], gr);
+          }
         }
       }
     }

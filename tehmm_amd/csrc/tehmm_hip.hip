@@ -2157,7 +2157,7 @@ void launch_estep(const tehmm_model *m, const IntervalTab &iv, const EmisTab &em
   constexpr int CPB = NT <= 44 ? 64 : 32;
   const EmisTab emf = n_iv > 256 ? without_lds_tables(em) : em;
   size_t lds = ((size_t)4 * CPB * (NT + 1) + 4 * CPB + 5 * NT + (size_t)emf.lds_rows * NT) * sizeof(double);
-  size_t lds2 = (size_t)std::max(1, m->lds_rows) * NT * sizeof(double);
+  size_t lds2 = (size_t)std::max(1, m->lds_rows) * NT * sizeof(double) + (size_t)3 * m->K * sizeof(int) + 16;
   if (ratio) {
     allow_lds(k_fb_coop<NT, CPB, true>, lds);
     hipLaunchKernelGGL((k_fb_coop<NT, CPB, true>), dim3(n_iv), dim3(256), lds, st, iv, emf, m->N, m->A.p,
