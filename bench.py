@@ -318,6 +318,16 @@ def extras(args, model, hm, hb, obs, offs, lens, device, torch, mk_model):
         hbv.close()
         hmv.close()
         del ob
+    # (3a) BASELINE configs[2] at the alyrata track-XML shape: K = 32 (15 multinomial + 14 gaussian / 250 bins + 3 binary)
+    mdl = synth.make_model(N_STATES, synth.CONFIG3B_SYMBOLS, synth.CONFIG3B_GAUSSIAN, seed=0)
+    ob = gen_obs_torch(mdl, lens[:sub], seed=34, device=device)
+    hmv = mk_model(mdl)
+    hbv = HipBatch(ob.data_ptr(), o3, device_ptrs=True, K=mdl.n_tracks)
+    d = time_eval(hmv, hbv, torch, viterbi=True, posterior=True)
+    ex["config3b_32_tracks"] = rate(n3, d, positions=n3, kernel_ms=hbv.timing())
+    hbv.close()
+    hmv.close()
+    del ob
     # (3b) state counts between the 36 the VALU lane kernels were first built for and the 64-lane limit
     for ns in (50, 60):
         mdl = synth.make_model(ns, synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=0)

@@ -288,6 +288,7 @@ CHUNK_CONFIGS = [
     {"TEHMM_SPEC_CHUNK": "512", "TEHMM_LANE_SUB": "256", "TEHMM_LANE_MFMA": "1"},
     {"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "128", "TEHMM_LANE_WARMUP": "24", "TEHMM_FB_RUNS": "0"},
     {"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "64", "TEHMM_VIT_RUNS": "0"},   # one verification per chunk
+    {"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "64", "TEHMM_FUSED": "0"},      # round-1 posterior pipeline (K > 78)
 ]
 
 
@@ -300,7 +301,7 @@ def test_chunk_parallel_sparse_model(hip, monkeypatch, cfg):
     from tehmm_amd.engine import HipBatch, HipModel
     from oracle import oracle
     for k in ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_LANE_VIT", "TEHMM_LANE_P0",
-              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS", "TEHMM_VIT_RUNS"):
+              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS", "TEHMM_VIT_RUNS", "TEHMM_FUSED"):
         monkeypatch.delenv(k, raising=False)
     for k, v in CHUNK_CONFIGS[cfg].items():
         monkeypatch.setenv(k, v)
@@ -330,7 +331,7 @@ def test_chunk_parallel_deep_emission_drops(hip, monkeypatch, cfg):
     from tehmm_amd.engine import HipBatch, HipModel
     from oracle import oracle
     for k in ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_LANE_VIT", "TEHMM_LANE_P0",
-              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS", "TEHMM_VIT_RUNS"):
+              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS", "TEHMM_VIT_RUNS", "TEHMM_FUSED"):
         monkeypatch.delenv(k, raising=False)
     for k, v in CHUNK_CONFIGS[cfg].items():
         monkeypatch.setenv(k, v)
@@ -362,7 +363,7 @@ def test_chunk_parallel_paths(hip, monkeypatch, cfg, N):
     from tehmm_amd.engine import HipBatch, HipModel
     from oracle import oracle
     for k in ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_LANE_VIT", "TEHMM_LANE_P0",
-              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS", "TEHMM_VIT_RUNS"):
+              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS", "TEHMM_VIT_RUNS", "TEHMM_FUSED"):
         monkeypatch.delenv(k, raising=False)
     for k, v in CHUNK_CONFIGS[cfg].items():
         monkeypatch.setenv(k, v)
@@ -402,7 +403,7 @@ def test_config_sizes_chunk_parallel_vs_sequential(hip, monkeypatch):
     from tehmm_amd import synth
     from tehmm_amd.engine import HipBatch, HipModel
     for k in ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_LANE_VIT", "TEHMM_LANE_P0",
-              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS", "TEHMM_VIT_RUNS"):
+              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS", "TEHMM_VIT_RUNS", "TEHMM_FUSED"):
         monkeypatch.delenv(k, raising=False)
     model = synth.make_model(35, synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=0)
     rs = np.random.RandomState(123)
@@ -449,7 +450,7 @@ def test_chunk_parallel_call_sequences(hip, monkeypatch):
     from tehmm_amd.engine import HipBatch, HipModel
     from oracle import oracle
     for k in ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_LANE_VIT", "TEHMM_LANE_P0",
-              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS", "TEHMM_VIT_RUNS"):
+              "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS", "TEHMM_VIT_RUNS", "TEHMM_FUSED"):
         monkeypatch.delenv(k, raising=False)
     model = synth.make_model(35, seed=9)
     lens = [3000, 26000, 50000]
