@@ -729,9 +729,27 @@ static int ensure_beta(tehmm_batch *b, const tehmm_model *m) {
   return TEHMM_OK;
 }
 
+// 64 <= N <= 128: the four-wave sequential kernels (k_*_wide); TEHMM_WIDE=0 selects the one-wave kernels
+static bool use_wide() {
+  const char *s = std::getenv("TEHMM_WIDE");
+  return !(s && std::atoi(s) == 0);
+}
+
 template <int SPL>
 static void launch_viterbi(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv,
                            const EmisTab &em, bool ratio, hipStream_t st) {
+  if (use_wide() && m->NP / 4 <= TEHMM_WIDE_QM && wide_lds_bytes(em.lds_rows, m->NP) <= 160 * 1024) {
+    const size_t lds = wide_lds_bytes(em.lds_rows, m->NP);
+    allow_lds(k_viterbi_wide<true>, lds);
+    allow_lds(k_viterbi_wide<false>, lds);
+    if (ratio)
+      hipLaunchKernelGGL((k_viterbi_wide<true>), dim3(b->n), dim3(256), lds, st, iv, em, m->N, m->NP, m->lt.p, m->pi.p,
+                         (const double *)b->ratios.p, b->TBW, b->tb.p, b->last_state.p, b->vit_lp.p);
+    else
+      hipLaunchKernelGGL((k_viterbi_wide<false>), dim3(b->n), dim3(256), lds, st, iv, em, m->N, m->NP, m->lt.p, m->pi.p,
+                         (const double *)nullptr, b->TBW, b->tb.p, b->last_state.p, b->vit_lp.p);
+    return;
+  }
   size_t lds = ((size_t)m->N * m->NP + (TEHMM_PB + 2) * 64 * SPL) * sizeof(double);
   allow_lds(k_viterbi<SPL, true, false>, lds);
   allow_lds(k_viterbi<SPL, false, false>, lds);
@@ -748,6 +766,17 @@ static void launch_viterbi(tehmm_batch *b, const tehmm_model *m, const IntervalT
 template <int SPL>
 static void launch_posterior(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv,
                              const EmisTab &em, hipStream_t st, hipEvent_t mid) {
+  if (use_wide() && m->NP / 4 <= TEHMM_WIDE_QM && wide_lds_bytes(em.lds_rows, m->NP) <= 160 * 1024) {
+    const size_t lds = wide_lds_bytes(em.lds_rows, m->NP);
+    allow_lds(k_forward_wide<false>, lds);
+    allow_lds(k_backward_wide<false, true>, lds);
+    hipLaunchKernelGGL((k_forward_wide<false>), dim3(b->n), dim3(256), lds, st, iv, em, m->N, m->NP, m->A.p, m->lt.p,
+                       m->pi.p, (const double *)nullptr, b->post.p, b->fwd_lp.p, b->first_good.p);
+    (void)hipEventRecord(mid, st);
+    hipLaunchKernelGGL((k_backward_wide<false, true>), dim3(b->n), dim3(256), lds, st, iv, em, m->N, m->NP, m->AT.p,
+                       m->lt.p, (const double *)nullptr, b->post.p, b->first_good.p);
+    return;
+  }
   size_t ldsF = ((size_t)m->N * m->NP + (TEHMM_PB + 2) * 64 * SPL + TEHMM_PB) * sizeof(double);
   size_t ldsB = ((size_t)m->N * m->NP + (TEHMM_PB + 2) * 64 * SPL) * sizeof(double);
   allow_lds(k_forward_lin<SPL, false>, ldsF);

@@ -942,4 +942,442 @@ __global__ __launch_bounds__(64) void k_backward_lin(IntervalTab iv, EmisTab em,
   }
 }
 
+
+// ==========================================================================================
+// "Wide" sequential kernels for 64 <= N <= 128 (BASELINE config 5): one workgroup of four waves per
+// interval instead of one wave.  Wave w owns the from-states [w Q, (w + 1) Q), Q = NP / 4, for ALL to-states
+// (two per lane) and keeps its quarter of the transition matrix in registers (2 x 33 doubles per lane: the LDS
+// copy of the one-wave kernels cost two LDS reads per candidate); the state vector is read from LDS as a
+// broadcast.  Per step: partial results -> LDS -> ONE workgroup barrier -> every wave combines the four
+// partials (same arithmetic, so the four private copies of the new vector agree) -> next step.  The emission
+// rows of a block of TEHMM_PB positions are computed by the four waves side by side.
+// Arithmetic: Viterbi candidates are formed exactly as in k_viterbi and compared in ascending from-order (inside a
+// wave, then wave 0..3 with a strict '>'), so path and score are bit-identical; forward / backward sum the four
+// partial dot products pairwise (tolerance 1e-6, like every scaled-linear kernel here).
+// LDS (doubles): ring [PB][128] | vown [4][2][128] | pval [2][4][128] | parg (int) [2][4][128] | ms [PB] (+8) |
+//                ltab [lds_rows][NP]
+// ==========================================================================================
+#define TEHMM_WIDE_QM 33
+#define TEHMM_WIDE_W 128
+#define TEHMM_WIDE_FIXED (TEHMM_PB * TEHMM_WIDE_W + 8 * TEHMM_WIDE_W + 8 * TEHMM_WIDE_W + 4 * TEHMM_WIDE_W + TEHMM_PB + 8)
+__host__ __device__ inline size_t wide_lds_bytes(int lds_rows, int NP) {
+  return ((size_t)TEHMM_WIDE_FIXED + (size_t)lds_rows * NP) * sizeof(double);
+}
+__device__ __forceinline__ double *wide_stage_table(const EmisTab &em, double *sm) {
+  double *ltab = sm + TEHMM_WIDE_FIXED;
+  for (int i = threadIdx.x; i < em.lds_rows * em.NP; i += blockDim.x) ltab[i] = em.ltab_src[i];
+  return ltab;
+}
+
+// Emission row of one position for the two states of a lane, small tracks from the LDS copy of their rows
+// (ltab [lds_rows][NP], staged once per workgroup), the others from the global table (L2).  The rows of four
+// tracks are requested together and then added in track order (the reference's operation order,
+// _emission.pyx:65-72); the LDS / global choice is a pointer select (flat loads), not a branch.
+__device__ __forceinline__ void emis_log_wide(const EmisTab &e, const double *ltab, int64_t gpos, int lane, int N,
+                                              double (&x)[2]) {
+  const uint32_t *row = e.obs32 + gpos * e.KPW;
+  x[0] = 0.0;
+  x[1] = 0.0;
+  const int j0 = lane < N ? lane : 0, j1 = lane + 64 < N ? lane + 64 : 0;
+  for (int k0 = 0; k0 < e.K; k0 += 4) {
+    double v[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = min(k0 + u, e.K - 1);
+      const uint32_t wd = row[k >> 2];
+      const int sym = (int)((wd >> ((k & 3) * 8)) & 0xffu);
+      const bool inr = sym < e.rowcnt[k];
+      const int lb = e.ldsbase[k];
+      const double *tr = lb >= 0 ? ltab + (size_t)(inr ? lb + sym : e.lds_zero) * e.NP
+                                 : e.tab + (int64_t)(inr ? e.rowbase[k] + sym : e.zero_row) * e.NP;
+      v[u][0] = tr[j0];
+      v[u][1] = tr[j1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (k0 + u < e.K) {
+        x[0] += v[u][0];
+        x[1] += v[u][1];
+      }
+  }
+  x[0] *= e.normalize;
+  x[1] *= e.normalize;
+  if (e.ratios) {
+    const double r = e.ratios[gpos];
+    x[0] *= r;
+    x[1] *= r;
+  }
+}
+
+// emission rows of one block: every wave computes the positions p = w (mod 4); before the first emittable row of
+// the interval (`seen` false at the block start) every wave walks ALL positions in order so that the leading-rows
+// quirk (_emission.pyx:73-80) stays sequential -- that only ever happens in the first blocks of an interval.
+// MODE 0: log rows (Viterbi); MODE 1: exp(row - max) rows + ms (forward); fg = first emittable position.
+template <int MODE, bool TRATIO>
+__device__ __forceinline__ void wide_emission_block(const EmisTab &em, int64_t gpos0, int64_t t0, int np, int lane, int w,
+                                                    int N, const double (&ltd)[2], const double *tratios, bool &seen,
+                                                    int64_t &fg, double *ring, double *ms, const double *ltab) {
+  const bool slow = !seen;
+  for (int p = slow ? 0 : w; p < np; p += slow ? 1 : 4) {
+    double x[2];
+    emis_log_wide(em, ltab, gpos0 + p, lane, N, x);
+    if (!seen) {
+      const double m0 = row_max<2>(x, lane, N);
+      if (m0 > -1e20) { seen = true; fg = t0 + p; }
+      else { x[0] = 0.0; x[1] = 0.0; }
+    }
+    if (slow && (p & 3) != w) continue;
+    if (MODE == 1) {
+      if (TRATIO) {
+        const double r = tratios[gpos0 + p];
+        if (r > 1.) { x[0] += ltd[0] * (r - 1.); x[1] += ltd[1] * (r - 1.); }
+      }
+      const double m = row_max<2>(x, lane, N);
+      ring[p * TEHMM_WIDE_W + lane] = exp(x[0] - m);
+      ring[p * TEHMM_WIDE_W + lane + 64] = exp(x[1] - m);
+      if (lane == 0) ms[p] = m;
+    } else {
+      ring[p * TEHMM_WIDE_W + lane] = x[0];
+      ring[p * TEHMM_WIDE_W + lane + 64] = x[1];
+    }
+  }
+}
+
+template <bool RATIO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_viterbi_wide(IntervalTab iv, EmisTab em, int N, int NP, const double *g_lt, const double *g_pi,
+                    const double *tratios, int TBW, uint8_t *tb, int *last_state, double *logprob) {
+  extern __shared__ double sm[];
+  constexpr int W = TEHMM_WIDE_W, QM = TEHMM_WIDE_QM;
+  double *ring = sm;
+  double *vown = ring + TEHMM_PB * W;
+  double *pval = vown + 8 * W;
+  int *parg = (int *)(pval + 8 * W);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int id = iv.order[blockIdx.x];
+  const int64_t T = iv.len[id];
+  const int64_t p0 = iv.pos0[id];
+  if (T <= 0) return;
+  const int Q = NP / 4, f0 = w * Q;
+  double ltq[2][QM], ltd[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int j = lane + 64 * s;
+    ltd[s] = j < N ? g_lt[(size_t)j * NP + j] : 0.0;
+#pragma unroll
+    for (int i = 0; i < QM; ++i) {
+      const int f = f0 + i;
+      ltq[s][i] = (i < Q && f < N && j < N) ? g_lt[(size_t)f * NP + j] : -INFINITY;
+    }
+  }
+  const double lt00 = g_lt[0];
+  double *vmine = vown + w * 2 * W;
+  vmine[lane] = vmine[lane + 64] = vmine[W + lane] = vmine[W + lane + 64] = -INFINITY;
+  const double *ltab = wide_stage_table(em, sm);
+  __syncthreads();
+  bool seen = false;
+  int64_t fg = T;
+  int cur = 0;
+  for (int64_t t0 = 0; t0 < T; t0 += TEHMM_PB) {
+    const int np = (int)min((int64_t)TEHMM_PB, T - t0);
+    wide_emission_block<0, false>(em, p0 + t0, t0, np, lane, w, N, ltd, nullptr, seen, fg, ring, nullptr, ltab);
+    __syncthreads();
+    for (int p = 0; p < np; ++p) {
+      const int64_t t = t0 + p;
+      const double b[2] = {ring[p * W + lane], ring[p * W + lane + 64]};
+      double r = 0.0;
+      if (RATIO) r = tratios[p0 + t];
+      const double *vp = vmine + cur * W;
+      double *vn = vmine + (cur ^ 1) * W;
+      if (t == 0) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int j = lane + 64 * s;
+          double v = (j < N ? g_pi[j] : -INFINITY) + b[s];
+          if (RATIO && r > 1.) v += ltd[s] * (r - 1.);
+          vn[j] = j < N ? v : -INFINITY;
+        }
+      } else {
+        const bool rg = RATIO && r > 1.;
+        const double rm1 = r - 1.;
+        double best[2] = {-INFINITY, -INFINITY};
+        int arg[2] = {0, 0};
+        if (w == 0) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            double c = (vp[0] + ltq[s][0]) + b[s];
+            if (RATIO) {
+              c += ltd[s] * r;
+              if (lane + 64 * s == 0) c -= lt00;
+            }
+            best[s] = c;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < QM; ++i) {
+          if (i == 0 && w == 0) continue;                    // (uniform per wave)
+          const double vf = vp[min(f0 + i, W - 1)];
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            double c = (vf + ltq[s][i]) + b[s];
+            if (rg) c += ltd[s] * rm1;
+            if (c > best[s]) { best[s] = c; arg[s] = f0 + i; }
+          }
+        }
+        const int par = (int)(t & 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          pval[(par * 4 + w) * W + lane + 64 * s] = best[s];
+          parg[(par * 4 + w) * W + lane + 64 * s] = arg[s];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int j = lane + 64 * s;
+          double fin = pval[(par * 4 + 0) * W + j];
+          int fa = parg[(par * 4 + 0) * W + j];
+#pragma unroll
+          for (int ww = 1; ww < 4; ++ww) {
+            const double c = pval[(par * 4 + ww) * W + j];
+            if (c > fin) { fin = c; fa = parg[(par * 4 + ww) * W + j]; }
+          }
+          vn[j] = j < N ? fin : -INFINITY;
+          if (w == 0 && j < N) tb[(p0 + t) * TBW + j] = (uint8_t)fa;
+        }
+      }
+      cur ^= 1;
+    }
+    __syncthreads();
+  }
+  // np.argmax over V[T-1] (first maximum; a NaN wins as soon as it is met)
+  if (threadIdx.x == 0) {
+    const double *v = vmine + cur * W;
+    int last = 0;
+    double m = v[0];
+    if (m == m) {
+      for (int j = 1; j < N; ++j) {
+        const double x = v[j];
+        if (x != x) { last = j; break; }
+        if (x > m) { m = x; last = j; }
+      }
+    }
+    last_state[id] = last;
+    logprob[id] = v[last];
+  }
+}
+
+template <bool TRATIO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_forward_wide(IntervalTab iv, EmisTab em, int N, int NP, const double *g_A, const double *g_lt,
+                    const double *g_pi, const double *tratios, double *post, double *fwd_logprob,
+                    int64_t *first_good) {
+  extern __shared__ double sm[];
+  constexpr int W = TEHMM_WIDE_W, QM = TEHMM_WIDE_QM;
+  double *ring = sm;
+  double *vown = ring + TEHMM_PB * W;
+  double *pval = vown + 8 * W;
+  double *ms = pval + 8 * W + 4 * W;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int id = iv.order[blockIdx.x];
+  const int64_t T = iv.len[id];
+  const int64_t p0 = iv.pos0[id];
+  if (T <= 0) return;
+  double *out = post + iv.out0[id] * N;
+  const int Q = NP / 4, f0 = w * Q;
+  double aq[2][QM], ltd[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int j = lane + 64 * s;
+    ltd[s] = j < N ? g_lt[(size_t)j * NP + j] : 0.0;
+#pragma unroll
+    for (int i = 0; i < QM; ++i) {
+      const int f = f0 + i;
+      aq[s][i] = (i < Q && f < N && j < N) ? g_A[(size_t)f * NP + j] : 0.0;
+    }
+  }
+  double *vmine = vown + w * 2 * W;
+  vmine[lane] = vmine[lane + 64] = vmine[W + lane] = vmine[W + lane + 64] = 0.0;
+  const double *ltab = wide_stage_table(em, sm);
+  __syncthreads();
+  bool seen = false;
+  int64_t fg = T;
+  int cur = 0, eprev = 0;
+  double Ecum = 0.0, Mcum = 0.0;
+  double a[2] = {0.0, 0.0};
+  for (int64_t t0 = 0; t0 < T; t0 += TEHMM_PB) {
+    const int np = (int)min((int64_t)TEHMM_PB, T - t0);
+    wide_emission_block<1, TRATIO>(em, p0 + t0, t0, np, lane, w, N, ltd, tratios, seen, fg, ring, ms, ltab);
+    __syncthreads();
+    for (int p = 0; p < np; ++p) {
+      const int64_t t = t0 + p;
+      const double *vp = vmine + cur * W;
+      double *vn = vmine + (cur ^ 1) * W;
+      Mcum += ms[p];
+      if (t == 0) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int j = lane + 64 * s;
+          a[s] = j < N ? exp(g_pi[j]) * ring[p * W + j] : 0.0;
+        }
+      } else {
+        double acc[2] = {0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < QM; ++i) {
+          const double vf = vp[min(f0 + i, W - 1)];
+          acc[0] = fma(vf, aq[0][i], acc[0]);
+          acc[1] = fma(vf, aq[1][i], acc[1]);
+        }
+        const int par = (int)(t & 1);
+        pval[(par * 4 + w) * W + lane] = acc[0];
+        pval[(par * 4 + w) * W + lane + 64] = acc[1];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int j = lane + 64 * s;
+          const double sum = (pval[(par * 4 + 0) * W + j] + pval[(par * 4 + 1) * W + j]) +
+                             (pval[(par * 4 + 2) * W + j] + pval[(par * 4 + 3) * W + j]);
+          a[s] = j < N ? ldexp(sum * ring[p * W + j], -eprev) : 0.0;
+        }
+        Ecum += (double)eprev;
+      }
+      int e = -1022;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int j = lane + 64 * s;
+        vn[j] = a[s];
+        if (j < N) {
+          if (w == 0) out[t * N + j] = a[s];
+          e = max(e, exp_of(a[s]));
+        }
+      }
+      eprev = wave_max_i32(e);
+      cur ^= 1;
+    }
+    __syncthreads();
+  }
+  double tot = wave_sum_f64(a[0] + a[1]);
+  if (threadIdx.x == 0) {
+    fwd_logprob[id] = log(tot) + Ecum * 0.6931471805599453 + Mcum;
+    first_good[id] = fg;
+  }
+}
+
+template <bool TRATIO, bool EPS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_backward_wide(IntervalTab iv, EmisTab em, int N, int NP, const double *g_AT, const double *g_lt,
+                     const double *tratios, double *post, const int64_t *first_good) {
+  extern __shared__ double sm[];
+  constexpr int W = TEHMM_WIDE_W, QM = TEHMM_WIDE_QM;
+  double *ring = sm;
+  double *vown = ring + TEHMM_PB * W;
+  double *pval = vown + 8 * W;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int id = iv.order[blockIdx.x];
+  const int64_t T = iv.len[id];
+  const int64_t p0 = iv.pos0[id];
+  if (T <= 0) return;
+  double *out = post + iv.out0[id] * N;
+  const int64_t fg = first_good[id];
+  const int Q = NP / 4, f0 = w * Q;
+  double atq[2][QM], ltd[2];                  // atq[s][i] = A[state of slot s][f0 + i]
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int j = lane + 64 * s;
+    ltd[s] = j < N ? g_lt[(size_t)j * NP + j] : 0.0;
+#pragma unroll
+    for (int i = 0; i < QM; ++i) {
+      const int f = f0 + i;
+      atq[s][i] = (i < Q && f < N && j < N) ? g_AT[(size_t)f * NP + j] : 0.0;
+    }
+  }
+  double *wmine = vown + w * 2 * W;
+  wmine[lane] = wmine[lane + 64] = 0.0;
+  const double *ltab = wide_stage_table(em, sm);
+  __syncthreads();
+  const double eps = 1.1920928955078125e-07;
+  const double epsden = 1.0 + (double)N * eps;
+  double beta[2];
+  int eprev = 0;
+  {   // position T-1: beta = 1
+    double g[2], tot = 0.0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int j = lane + 64 * s;
+      beta[s] = j < N ? 1.0 : 0.0;
+      g[s] = j < N ? out[(T - 1) * N + j] : 0.0;
+      tot += g[s];
+    }
+    tot = wave_sum_f64(tot);
+    __syncthreads();                          // every wave has read the alpha row before wave 0 overwrites it
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int j = lane + 64 * s;
+      double pr = g[s] / tot;
+      if (EPS) pr = (pr + eps) / epsden;
+      if (w == 0 && j < N) out[(T - 1) * N + j] = pr;
+    }
+    eprev = 1;
+  }
+  for (int64_t thi = T - 2; thi >= 0; thi -= TEHMM_PB) {
+    const int np = (int)min((int64_t)TEHMM_PB, thi + 1);
+    for (int p = w; p < np; p += 4) {   // ring[p] <- bh'[(thi - p) + 1]
+      const int64_t u = thi - p + 1;
+      double x[2];
+      emis_log_wide(em, ltab, p0 + u, lane, N, x);
+      if (u < fg) { x[0] = 0.0; x[1] = 0.0; }
+      if (TRATIO) {
+        const double r = tratios[p0 + u];
+        if (r > 1.) { x[0] += ltd[0] * (r - 1.); x[1] += ltd[1] * (r - 1.); }
+      }
+      const double m = row_max<2>(x, lane, N);
+      ring[p * W + lane] = exp(x[0] - m);
+      ring[p * W + lane + 64] = exp(x[1] - m);
+    }
+    __syncthreads();
+    for (int p = 0; p < np; ++p) {
+      const int64_t t = thi - p;
+      double av[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int j = lane + 64 * s;
+        av[s] = j < N ? out[t * N + j] : 0.0;          // scaled alpha row (independent load)
+        wmine[j] = j < N ? ring[p * W + j] * beta[s] : 0.0;
+      }
+      double acc[2] = {0.0, 0.0};
+#pragma unroll
+      for (int i = 0; i < QM; ++i) {
+        const double wf = wmine[min(f0 + i, W - 1)];
+        acc[0] = fma(atq[0][i], wf, acc[0]);
+        acc[1] = fma(atq[1][i], wf, acc[1]);
+      }
+      const int par = (int)(t & 1);
+      pval[(par * 4 + w) * W + lane] = acc[0];
+      pval[(par * 4 + w) * W + lane + 64] = acc[1];
+      __syncthreads();
+      int e = -1022;
+      double g[2], tot = 0.0;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int j = lane + 64 * s;
+        const double sum = (pval[(par * 4 + 0) * W + j] + pval[(par * 4 + 1) * W + j]) +
+                           (pval[(par * 4 + 2) * W + j] + pval[(par * 4 + 3) * W + j]);
+        beta[s] = j < N ? ldexp(sum, -eprev) : 0.0;
+        e = max(e, exp_of(beta[s]));
+        g[s] = av[s] * beta[s];
+        tot += g[s];
+      }
+      eprev = wave_max_i32(e);
+      tot = wave_sum_f64(tot);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int j = lane + 64 * s;
+        double pr = g[s] / tot;
+        if (EPS) pr = (pr + eps) / epsden;
+        if (w == 0 && j < N) out[t * N + j] = pr;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace tehmm
