@@ -1004,7 +1004,11 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
   const size_t rows = (size_t)std::max(1, lw.n_groups) * L * 64;        // item-interleaved positions
   const size_t vecs = (size_t)std::max(1, lw.n_groups) * 64 * m->NP;
   if (want_fb && !lw.pre_f.p) {
-    if (fused_fb) HIPCHK(lw.AL32.alloc((size_t)std::max(1, lw.n_groups) * L * 512 * al32_pairs(m->NP)));
+    if (fused_fb) {
+      const size_t na = (size_t)std::max(1, lw.n_groups) * L * 512 * al32_pairs(m->NP);
+      HIPCHK(lw.AL32.alloc(na));
+      HIPCHK(hipMemset(lw.AL32.p, 0, na * sizeof(float)));      // (slots of padding states are read, never NaN)
+    }
     else HIPCHK(lw.AL.alloc(rows * m->NP));
     HIPCHK(lw.pre_f.alloc(vecs));
     HIPCHK(lw.end_f.alloc(vecs));
@@ -1025,7 +1029,11 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
     HIPCHK(lw.chk.alloc((size_t)std::max(1, lw.n_groups) * 64 * (size_t)(L / 64) * m->NP));
     HIPCHK(lw.chkf.alloc((size_t)std::max(1, lw.n_groups) * 64 * (size_t)(L / 64) * m->NP));
   }
-  if (want_fb && fused_fb && !lw.AL32.p) HIPCHK(lw.AL32.alloc((size_t)std::max(1, lw.n_groups) * L * 512 * al32_pairs(m->NP)));
+  if (want_fb && fused_fb && !lw.AL32.p) {
+    const size_t na = (size_t)std::max(1, lw.n_groups) * L * 512 * al32_pairs(m->NP);
+    HIPCHK(lw.AL32.alloc(na));
+    HIPCHK(hipMemset(lw.AL32.p, 0, na * sizeof(float)));
+  }
   if (want_fb && !fused_fb && !lw.AL.p) HIPCHK(lw.AL.alloc(rows * m->NP));
   if (want_fb && !fused_fb && !lw.BH.p) {
     HIPCHK(lw.BE.alloc(rows * m->NP));

@@ -957,6 +957,40 @@ __global__ __launch_bounds__(64) void k_backward_lin(IntervalTab iv, EmisTab em,
 // LDS (doubles): ring [PB][128] | vown [4][2][128] | pval [2][4][128] | parg (int) [2][4][128] | ms [PB] (+8) |
 //                ltab [lds_rows][NP]
 // ==========================================================================================
+// wave-wide max of an int / sum of a double without LDS shuffles (six dependent ds_bpermute round trips cost ~700
+// cycles per step in the sequential kernels): xor butterfly inside the 16-lane rows by DPP, the rows by permlane swaps
+__device__ __forceinline__ int wave_max_i32_dpp(int v) {
+  v = max(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true));     // quad_perm [1,0,3,2]
+  v = max(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true));     // quad_perm [2,3,0,1]
+  v = max(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true));    // row_half_mirror
+  v = max(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true));    // row_mirror
+  const auto a = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+  v = max((int)a[0], (int)a[1]);
+  const auto c = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+  return max((int)c[0], (int)c[1]);
+}
+__device__ __forceinline__ double wave_sum_f64_dpp(double v) {
+#define TEHMM_DPP_ADD(CTRL)                                                                                  \
+  do {                                                                                                       \
+    const int lo_ = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);                       \
+    const int hi_ = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);                       \
+    v += __hiloint2double(hi_, lo_);                                                                         \
+  } while (0)
+  TEHMM_DPP_ADD(0xB1);
+  TEHMM_DPP_ADD(0x4E);
+  TEHMM_DPP_ADD(0x141);
+  TEHMM_DPP_ADD(0x140);
+#undef TEHMM_DPP_ADD
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  const double t1 = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+  const unsigned lo1 = __double2loint(t1), hi1 = __double2hiint(t1);
+  const auto c = __builtin_amdgcn_permlane16_swap(lo1, lo1, false, false);
+  const auto d = __builtin_amdgcn_permlane16_swap(hi1, hi1, false, false);
+  return __hiloint2double((int)d[0], (int)c[0]) + __hiloint2double((int)d[1], (int)c[1]);
+}
+
 #define TEHMM_WIDE_QM 33
 #define TEHMM_WIDE_W 128
 #define TEHMM_WIDE_FIXED (TEHMM_PB * TEHMM_WIDE_W + 8 * TEHMM_WIDE_W + 8 * TEHMM_WIDE_W + 4 * TEHMM_WIDE_W + TEHMM_PB + 8)
@@ -1250,7 +1284,7 @@ void k_forward_wide(IntervalTab iv, EmisTab em, int N, int NP, const double *g_A
           e = max(e, exp_of(a[s]));
         }
       }
-      eprev = wave_max_i32(e);
+      eprev = wave_max_i32_dpp(e);
       cur ^= 1;
     }
     __syncthreads();
@@ -1366,8 +1400,8 @@ void k_backward_wide(IntervalTab iv, EmisTab em, int N, int NP, const double *g_
         g[s] = av[s] * beta[s];
         tot += g[s];
       }
-      eprev = wave_max_i32(e);
-      tot = wave_sum_f64(tot);
+      eprev = wave_max_i32_dpp(e);
+      tot = wave_sum_f64_dpp(tot);
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int j = lane + 64 * s;

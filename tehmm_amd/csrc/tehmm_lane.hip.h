@@ -714,6 +714,8 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItem
 #ifndef TEHMM_P2_PF
 #define TEHMM_P2_PF 2      // emission values are requested this many output groups ahead
 #endif
+  // (a row of one group only -- NT = 4 -- has no "group after next" in the same or the following row)
+  constexpr int P2_PF = (TEHMM_P2_PF == 2 && NT / 4 >= 2) ? 2 : 1;
   double bny[4];
   bool pending = false;
   auto prefetch = [&](const double *row, int og) {
@@ -774,7 +776,7 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItem
         // x = max_f W[f] + tab[f][o]   (tab scalar; QUANT: it carries the from-index in its low bits)
 #pragma unroll
         for (int q = 0; q < 4; ++q) bc[q] = bnx[q];
-        if (TEHMM_P2_PF == 2) {
+        if (P2_PF == 2) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) bnx[q] = bny[q];
           if (og + 2 < NT / 4) prefetch2(bp, og + 2);
@@ -938,7 +940,7 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItem
     const double *bpn = B + (sn < 0 ? lane_row(lg, NT, nb, L + sn) : lane_row(lg, NT, item, sn));
     if (s == -Wu) {
       prefetch(bp, 0);
-      if (TEHMM_P2_PF == 2) prefetch2(bp, 1);
+      if (P2_PF == 2) prefetch2(bp, 1);
     }
     double rt = 1.0;
     if (RATIO) {

@@ -824,7 +824,9 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
             if (es && lane == 0) es[t] = e;
           }
           if (FUSED) {
-            if (live) al32[al32_index<NT>(lg, ifirst + t / lg.L, t % lg.L, jl)] = (float)v;
+            // (the padding states too: the backward lane pass multiplies them with its zero beta, and a stale
+            //  NaN / Inf bit pattern in a slot nobody wrote would turn the row's normalisation into NaN)
+            if (lane < NT) al32[al32_index<NT>(lg, ifirst + t / lg.L, t % lg.L, lane)] = live ? (float)v : 0.f;
           } else if (live) {
             brow[p * rstride] = v;
           }

@@ -354,7 +354,7 @@ def test_chunk_parallel_deep_emission_drops(hip, monkeypatch, cfg):
 
 
 @pytest.mark.parametrize("cfg", range(len(CHUNK_CONFIGS)))
-@pytest.mark.parametrize("N", [35, 20, 7, 50, 60])
+@pytest.mark.parametrize("N", [35, 20, 7, 50, 60, 3])
 def test_chunk_parallel_paths(hip, monkeypatch, cfg, N):
     """Every chunk-parallel code path (exact speculative Viterbi, speculative forward / backward,
     lane = item passes, their fix-up chains, jumps, ties, failed links) at chunk sizes small enough for

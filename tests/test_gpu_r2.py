@@ -362,6 +362,8 @@ def _mixed_ratios(T, seed, big=False):
     (35, {"TEHMM_SPEC_CHUNK": "1024"}, True),
     (20, {"TEHMM_SPEC_CHUNK": "512", "TEHMM_LANE_SUB": "128"}, False),
     (7, {"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "64"}, True),
+    (3, {"TEHMM_SPEC_CHUNK": "256"}, False),                 # one output group per row (NT = 4)
+    (2, {"TEHMM_SPEC_CHUNK": "512", "TEHMM_LANE_SUB": "256"}, True),
 ])
 def test_chunk_parallel_viterbi_with_segment_ratios(monkeypatch, N, env, big):
     """Decode on a segmented table (_hmm.pyx:229-247: lt[j][j] * (r - 1) for r > 1 on every candidate but the

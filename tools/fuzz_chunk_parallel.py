@@ -12,10 +12,10 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 long_mode = len(sys.argv) > 3 and sys.argv[3] == "long"     # few long intervals: several binades per interval
 KEYS = ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_LANE_WARMUP_VIT", "TEHMM_LANE_VIT",
-        "TEHMM_LANE_P0", "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS", "TEHMM_VIT_RUNS")
+        "TEHMM_LANE_P0", "TEHMM_LANE_MFMA", "TEHMM_FB_RUNS", "TEHMM_VIT_RUNS", "TEHMM_FUSED")
 bad = 0
 t_start = time.time()
-for case in range(n_cases):
+for case in range(int(os.environ.get("FUZZ_START", "0")), n_cases):
     rs = np.random.RandomState(seed0 + case)
     for k in KEYS:
         os.environ.pop(k, None)
@@ -36,6 +36,8 @@ for case in range(n_cases):
         env["TEHMM_VIT_RUNS"] = "0"
     if rs.rand() < 0.2:
         env["TEHMM_FB_RUNS"] = "0"
+    if rs.rand() < 0.15:
+        env["TEHMM_FUSED"] = "0"
     os.environ.update(env)
     N = int(rs.choice([2, 3, 5, 8, 13, 20, 27, 35, 36, 41, 50, 63]))
     K = int(rs.randint(1, 13))
@@ -52,7 +54,7 @@ for case in range(n_cases):
         model = synth.make_model(N, syms, gauss, seed=seed0 + case, sparse=float(rs.choice([0.0, 0.0, 0.3])))
     offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     obs = synth.sample_obs(model, int(offs[-1]), seed=case, missing=float(rs.choice([0.0, 0.05, 0.3])))
-    with_ratio = bool(rs.rand() < 0.25)
+    with_ratio = bool(rs.rand() < 0.4)
     ratios = synth.random_ratios(int(offs[-1]), seed=case) if with_ratio else None
     hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, normalize, model.symbols_per_track)
     hb = HipBatch(obs, offs, ratios)
@@ -68,7 +70,7 @@ for case in range(n_cases):
         status = "ok"
     except AssertionError as e:
         bad += 1
-        status = "MISMATCH " + str(e).splitlines()[0][:80]
+        status = "MISMATCH " + " | ".join(x.strip() for x in str(e).splitlines()[:8])[:400]
     t = hb.timing()
     print(case, status, "N", N, "K", K, "T", int(offs[-1]), env, "ratio" if with_ratio else "",
           {k.split(":")[1]: int(v) for k, v in t.items() if k.startswith("count:")}, flush=True)
