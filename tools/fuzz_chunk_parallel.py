@@ -40,6 +40,9 @@ for case in range(int(os.environ.get("FUZZ_START", "0")), n_cases):
         env["TEHMM_FUSED"] = "0"
     os.environ.update(env)
     N = int(rs.choice([2, 3, 5, 8, 13, 20, 27, 35, 36, 41, 50, 63]))
+    big_n = os.environ.get("FUZZ_BIGN") and rs.rand() < 0.7      # the four-wave sequential kernels (64 <= N <= 128)
+    if big_n:
+        N = int(rs.choice([64, 65, 77, 100, 127, 128]))
     K = int(rs.randint(1, 13))
     syms = [int(rs.choice([1, 2, 3, 5, 17, 100, 255])) for _ in range(K)]
     gauss = [k for k in range(K) if syms[k] >= 100 and rs.rand() < 0.5]
@@ -48,6 +51,8 @@ for case in range(int(os.environ.get("FUZZ_START", "0")), n_cases):
     lens = [int(x) for x in rs.choice([1, 7, 64, 300, 1500, 4097, 9000, 20000, 33000], size=int(rs.randint(1, 6)))]
     if rs.rand() < 0.5:
         lens.append(int(rs.randint(30000, 70000)))
+    if big_n:
+        lens = [int(x) for x in rs.choice([1, 7, 64, 300, 1500, 4097, 9000], size=int(rs.randint(1, 5)))]
     if long_mode:
         lens = [int(rs.randint(100000, 500000)) for _ in range(int(rs.randint(1, 4)))]
         N = int(rs.choice([5, 8, 20, 35, 36]))
