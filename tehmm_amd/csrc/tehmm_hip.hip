@@ -199,7 +199,7 @@ struct tehmm_batch {
   DBuf<int64_t> paths;
   DBuf<double> post;
   DBuf<uint8_t> tb;
-  DBuf<uint8_t> G, bstate;
+  DBuf<uint8_t> G, bstate, Gg, tstate;     // chunk maps, boundary states; tile maps and tile states of the two-level scan
   DBuf<double> beta;
   DBuf<int> dead;
   DBuf<int> last_state;
@@ -926,7 +926,7 @@ static void launch_vit_spec(tehmm_batch *b, const tehmm_model *m, const Interval
 template <int NT>
 static void launch_vit_fix(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em,
                            const VitChunks &vc, bool segmin, bool ratio, hipStream_t st) {
-  size_t lds = ((size_t)3 * 32 * (NT + 1) + 2 * 33 * (NT + 2) + (size_t)m->lds_rows * NT + 8) * sizeof(double);   // CPB = 32
+  size_t lds = ((size_t)3 * 32 * (NT + 1) + 2 * 33 * (NT + 2) + (size_t)m->lds_rows * NT + 16) * sizeof(double);   // CPB = 32
   allow_lds(k_vit_fix<NT, false>, lds);
   allow_lds(k_vit_fix<NT, true>, lds);
   if constexpr (NT <= 36) if (ratio) {
@@ -950,11 +950,12 @@ static void launch_vit_fix(tehmm_batch *b, const tehmm_model *m, const IntervalT
 static LaneGeom lane_geom(const LaneWork &lw);
 
 // Item length L (L | CS, 64 | L).  Every wave owns 64 items; 512 positions per item keep the warm-up
-// overhead below 20 %, 256 are used for small batches so that the 1024 SIMDs still get a wave each.
+// overhead below 20 %, 256 / 128 are used for small batches so that the 1024 SIMDs still get a wave each.
 // TEHMM_LANE_SUB overrides (0 disables the lane passes).
 static int lane_sub_size(int CS, int64_t total) {
   if (CS <= 0) return 0;
-  int L = total >= (int64_t)512 * 64 * 1024 ? 512 : 256;
+  // (measured: 10 Mb in one interval runs the lane passes in 16.1 ms with 128-position items, 18.2 with 256)
+  int L = total >= (int64_t)512 * 64 * 1024 ? 512 : (total >= (int64_t)256 * 64 * 1024 ? 256 : 128);
   if (const char *s = std::getenv("TEHMM_LANE_SUB")) {
     L = std::atoi(s);
     if (L <= 0) return 0;
@@ -1828,8 +1829,26 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     if (b->n_chunks > 0)
       hipLaunchKernelGGL(k_tb_compose, dim3((b->n_chunks + 3) / 4), dim3(256), 4 * tb_stage_bytes(b->TBW), st, iv, b->d_chunk_iv.p,
                          b->d_chunk0.p, b->n_chunks, m->N, m->NP, b->TBW, b->tb.p, b->G.p);
-    hipLaunchKernelGGL(k_tb_scan, dim3(std::max(1, b->n)), dim3(64), 0, st, iv, b->d_chunk0.p, m->NP,
-                       b->G.p, b->last_state.p, b->bstate.p, b->paths.p);
+    {
+      // long intervals: two-level scan (tiles of 64 chunk maps composed in parallel)
+      int64_t maxc = 0;
+      for (int i = 0; i < b->n; ++i) maxc = std::max<int64_t>(maxc, b->h_chunk0[(size_t)i + 1] - b->h_chunk0[(size_t)i]);
+      const int maxt = (int)((maxc + 63) / 64);
+      if (maxt > 8) {
+        const size_t ntile = (size_t)b->n_chunks / 64 + (size_t)b->n + 2;
+        HIPCHK(b->Gg.ensure(ntile * m->NP));
+        HIPCHK(b->tstate.ensure(ntile));
+        hipLaunchKernelGGL(k_tb_group, dim3(b->n, maxt), dim3(64), 0, st, iv, b->d_chunk0.p, m->NP, (const uint8_t *)b->G.p,
+                           b->Gg.p);
+        hipLaunchKernelGGL(k_tb_scan_top, dim3(b->n), dim3(64), 0, st, iv, b->d_chunk0.p, m->NP, (const uint8_t *)b->Gg.p,
+                           (const int *)b->last_state.p, b->tstate.p, b->paths.p);
+        hipLaunchKernelGGL(k_tb_scan_tiles, dim3(b->n, maxt), dim3(64), 0, st, iv, b->d_chunk0.p, m->NP,
+                           (const uint8_t *)b->G.p, (const uint8_t *)b->tstate.p, b->bstate.p);
+      } else {
+        hipLaunchKernelGGL(k_tb_scan, dim3(std::max(1, b->n)), dim3(64), 0, st, iv, b->d_chunk0.p, m->NP,
+                           b->G.p, b->last_state.p, b->bstate.p, b->paths.p);
+      }
+    }
     if (b->n_chunks > 0)
       hipLaunchKernelGGL(k_tb_fill, dim3((b->n_chunks + 3) / 4), dim3(256), 4 * tb_stage_bytes(b->TBW), st, iv,
                          b->n_chunks, b->d_chunk_iv.p, b->d_chunk0.p, b->TBW, b->tb.p, b->bstate.p,

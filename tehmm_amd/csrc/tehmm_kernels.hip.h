@@ -649,6 +649,86 @@ __global__ __launch_bounds__(64) void k_tb_scan(IntervalTab iv, const int64_t *c
     __syncthreads();
   }
 }
+// Two-level form of the scan for long intervals (a 10 Mb interval has 39 k chunk maps: 1.7 ms of dependent LDS
+// lookups in one wave).  Tiles of 64 chunk maps, counted from the END of the interval (tile ty covers the chunks
+// [nc - 64 ty - 64, nc - 64 ty)), are composed in parallel (k_tb_group: lane = state at the tile's upper end), one wave
+// per interval walks the tile maps (k_tb_scan_top), then every tile walks its own chunks from the state it was handed
+// (k_tb_scan_tiles).  Tile storage of interval id starts at chunk0[id] / 64 + id (never overlapping).
+__global__ __launch_bounds__(64) void k_tb_group(IntervalTab iv, const int64_t *chunk0, int NP, const uint8_t *G,
+                                                 uint8_t *Gg) {
+  __shared__ uint8_t rows[64 * 136];
+  const int id = blockIdx.x, ty = blockIdx.y, lane = threadIdx.x;
+  if (id >= iv.n || iv.len[id] <= 0) return;
+  const int64_t c0 = chunk0[id], nc = chunk0[id + 1] - c0;
+  const int64_t hi = nc - 64 * (int64_t)ty;
+  if (hi <= 0) return;
+  const int64_t lo = hi > 64 ? hi - 64 : 0;
+  const int n = (int)(hi - lo);
+  const uint8_t *src = G + (c0 + lo) * NP;
+  for (int i = lane; i < n * NP; i += 64) rows[i] = src[i];
+  __syncthreads();
+  const int64_t tile = c0 / 64 + id + ty;
+  for (int s0 = lane; s0 < NP; s0 += 64) {
+    int s = s0;
+    for (int c = n - 1; c >= 0; --c) s = rows[c * NP + s];
+    Gg[tile * NP + s0] = (uint8_t)s;
+  }
+}
+__global__ __launch_bounds__(64) void k_tb_scan_top(IntervalTab iv, const int64_t *chunk0, int NP, const uint8_t *Gg,
+                                                    const int *last_state, uint8_t *tstate, int64_t *paths) {
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ uint8_t rows[64 * 136];
+  __shared__ uint8_t bst[64];
+  const int id = blockIdx.x, lane = threadIdx.x;
+  if (id >= iv.n || iv.len[id] <= 0) return;
+  int s = last_state[id];
+  const int64_t c0 = chunk0[id], nc = chunk0[id + 1] - c0;
+  if (nc == 0) {
+    if (lane == 0) paths[iv.out0[id]] = s;
+    return;
+  }
+  const int64_t nt = (nc + 63) / 64, t0 = c0 / 64 + id;
+  for (int64_t lo = 0; lo < nt; lo += 64) {            // tiles ascend = positions descend
+    const int n = (int)min((int64_t)64, nt - lo);
+    const uint8_t *src = Gg + (t0 + lo) * NP;
+    for (int i = lane; i < n * NP; i += 64) rows[i] = src[i];
+    __syncthreads();
+    if (lane == 0) {
+      for (int c = 0; c < n; ++c) {
+        bst[c] = (uint8_t)s;
+        s = rows[c * NP + s];
+      }
+    }
+    __syncthreads();
+    s = __shfl(s, 0);
+    if (lane < n) tstate[t0 + lo + lane] = bst[lane];
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(64) void k_tb_scan_tiles(IntervalTab iv, const int64_t *chunk0, int NP, const uint8_t *G,
+                                                      const uint8_t *tstate, uint8_t *bstate) {
+  __shared__ uint8_t rows[64 * 136];
+  __shared__ uint8_t bst[64];
+  const int id = blockIdx.x, ty = blockIdx.y, lane = threadIdx.x;
+  if (id >= iv.n || iv.len[id] <= 0) return;
+  const int64_t c0 = chunk0[id], nc = chunk0[id + 1] - c0;
+  const int64_t hi = nc - 64 * (int64_t)ty;
+  if (hi <= 0) return;
+  const int64_t lo = hi > 64 ? hi - 64 : 0;
+  const int n = (int)(hi - lo);
+  const uint8_t *src = G + (c0 + lo) * NP;
+  for (int i = lane; i < n * NP; i += 64) rows[i] = src[i];
+  __syncthreads();
+  if (lane == 0) {
+    int s = tstate[c0 / 64 + id + ty];
+    for (int c = n - 1; c >= 0; --c) {
+      bst[c] = (uint8_t)s;
+      s = rows[c * NP + s];
+    }
+  }
+  __syncthreads();
+  if (lane < n) bstate[c0 + lo + lane] = bst[lane];
+}
 // fill: one wave per chunk: pointer rows staged in LDS, lane 0 walks them and leaves the states in LDS, the
 // wave writes the int64 path coalesced
 __global__ __launch_bounds__(256) void k_tb_fill(IntervalTab iv, int n_chunks, const int *chunk_iv, const int64_t *chunk0,

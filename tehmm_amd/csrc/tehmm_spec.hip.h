@@ -254,6 +254,10 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
   volatile int64_t *seqpos = (volatile int64_t *)(ltab + em.lds_rows * NT);
   volatile int *gen = (volatile int *)(seqpos + 4);
   volatile int *blen = gen + 2;         // [4] positions the chain really ran in the block of iteration it & 3
+  // the position a block WOULD jump to, published when the block starts (the decision falls 12..27 steps later):
+  // the emission wave prepares that block meanwhile, so a verified jump does not wait for its rows
+  volatile int64_t *tent = seqpos + 8;  // [4]
+  volatile int *tgen = (volatile int *)(tent + 4);
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
   const int id = iv.order[blockIdx.x];
@@ -266,6 +270,8 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
     seqpos[1] = seqpos[2] = seqpos[3] = T;
     *gen = 0;
     blen[0] = blen[1] = blen[2] = blen[3] = 0;
+    tent[0] = tent[1] = tent[2] = tent[3] = T;
+    *tgen = 0;
   }
   const int jl = min(lane, NT - 1);
   const bool live = lane < N;
@@ -352,6 +358,7 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
         double wrow = 0.0, wend = 0.0, delta = 0.0;
         bool jump = false;
         if (spec) {
+          if (lane == 0) { tent[(it + 1) & 3] = target; *tgen = it + 1; }
           wrow = vc.rows[((c * (vc.CS / TEHMM_VROW)) + (g - ct0) / TEHMM_VROW) * NT + jl];
           wend = trow[jl] + lkacc;        // exact: multiples of u inside one binade
         } else {
@@ -452,12 +459,28 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
       const int64_t prev = it > 0 ? seqpos[(it - 1) & 3] : T;
       if (cur >= T && prev >= T) break;
       int spins = 0;
-      while (*gen < it + 1) {
+      while (*gen < it + 1 && *tgen < it + 1) {
         __builtin_amdgcn_s_sleep(8);
         if (++spins > (1 << 26)) break;      // never expected; bounded so that the grid drains
       }
+      int64_t done = -1;                     // position whose rows already sit in the ring slot
+      if (*gen < it + 1 && *tgen >= it + 1 && seen) {
+        // only the tentative landing position is known yet: prepare it (every row up to it is emittable -- the
+        // jump would not be offered otherwise -- so the leading-rows state `seen` is not disturbed)
+        const int64_t tp = tent[(it + 1) & 3];
+        if (tp < T) {
+          const int np = (int)min((int64_t)CPB, T - tp);
+          emis_block<NT, false, true, false>(em, ltab, p0 + tp, np, lane, N, seen, nullptr, nullptr,
+                                             nullptr, bring + ((it + 1) % 3) * CPB * RS, RS, nullptr);
+          done = tp;
+        }
+      }
+      while (*gen < it + 1) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1 << 26)) break;
+      }
       const int64_t nx = seqpos[(it + 1) & 3];
-      if (nx < T) {
+      if (nx < T && nx != done) {
         const int np = (int)min((int64_t)CPB, T - nx);
         emis_block<NT, false, true, false>(em, ltab, p0 + nx, np, lane, N, seen, nullptr, nullptr,
                                            nullptr, bring + ((it + 1) % 3) * CPB * RS, RS, nullptr);
