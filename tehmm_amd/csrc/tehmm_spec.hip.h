@@ -321,9 +321,12 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
         const int64_t ct0 = vc.t0[c];
         const int e = vc.e[c];
         bool spec = e != TEHMM_SPEC_NONE && np == CPB && vc.ok[c] != 0;
-        // smallest recorded row >= cur + 12 (rank convergence takes 3-16 steps; a check that comes too
+        // smallest recorded row >= cur + TEHMM_FIX_MINSTEP (rank convergence takes 3-16 steps; a check that comes too
         // early simply fails and the next block tries again)
-        const int64_t g = ct0 + ((cur + 12 - ct0) / TEHMM_VROW) * TEHMM_VROW + (TEHMM_VROW - 1);
+#ifndef TEHMM_FIX_MINSTEP
+#define TEHMM_FIX_MINSTEP 12
+#endif
+        const int64_t g = ct0 + ((cur + TEHMM_FIX_MINSTEP - ct0) / TEHMM_VROW) * TEHMM_VROW + (TEHMM_VROW - 1);
         const int pg = (int)(g - cur);                          // in-block step of the check, 12..27
         int64_t target = ct0 + vc.CS;
         double smin = 0.0, lkacc = 0.0;
