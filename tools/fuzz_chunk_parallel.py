@@ -69,8 +69,8 @@ for case in range(int(os.environ.get("FUZZ_START", "0")), n_cases):
     try:
         assert_array_equal(hb.paths(), p_o)
         assert_array_equal(res["viterbi_logprob"], vlp_o)
-        # (one-symbol models have log P = 0 exactly: compare those absolutely, 1e-13 per position)
-        assert_allclose(res["forward_logprob"], flp_o, rtol=1e-6, atol=1e-9 + 1e-13 * float(offs[-1]))
+        # (one-symbol models have log P = 0 exactly: compare those absolutely, 5e-13 per position -- every verified jump carries ~1e-11 of log-scale rounding)
+        assert_allclose(res["forward_logprob"], flp_o, rtol=1e-6, atol=1e-9 + 5e-13 * float(offs[-1]))
         assert_allclose(hb.posteriors(), post_o, rtol=1e-6, atol=1e-15)
         status = "ok"
     except AssertionError as e:
