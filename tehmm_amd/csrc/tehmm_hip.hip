@@ -1834,7 +1834,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       int64_t maxc = 0;
       for (int i = 0; i < b->n; ++i) maxc = std::max<int64_t>(maxc, b->h_chunk0[(size_t)i + 1] - b->h_chunk0[(size_t)i]);
       const int maxt = (int)((maxc + 63) / 64);
-      if (maxt > 8) {
+      if (maxt > 8 && maxt <= 65535) {          // (grid.y limit: longer intervals keep the one-level scan)
         const size_t ntile = (size_t)b->n_chunks / 64 + (size_t)b->n + 2;
         HIPCHK(b->Gg.ensure(ntile * m->NP));
         HIPCHK(b->tstate.ensure(ntile));
