@@ -21,6 +21,11 @@
 #include <stdint.h>
 
 #define TEHMM_WAVE 64
+// issue priority of the latency kernels (fix-up chains, traceback walks) next to co-resident throughput waves
+#ifndef TEHMM_PRIO_HI
+#define TEHMM_PRIO_HI 3
+#define TEHMM_PRIO_LO 2
+#endif
 #define TEHMM_MAX_TRACKS 128
 #define TEHMM_PB 16          // positions per emission phase (LDS ring depth)
 #define TEHMM_TB_CHUNK 256   // traceback chunk length
@@ -583,7 +588,7 @@ __global__ __launch_bounds__(256) void k_tb_compose(IntervalTab iv, const int *c
                                                     const int64_t *chunk0, int n_chunks, int N, int NP, int TBW,
                                                     const uint8_t *tb, uint8_t *G) {
   extern __shared__ uint8_t tb_lds[];
-  __builtin_amdgcn_s_setprio(3);      // latency kernel: issue ahead of co-resident throughput waves
+  __builtin_amdgcn_s_setprio(TEHMM_PRIO_HI);      // latency kernel: issue ahead of co-resident throughput waves
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 4 + w;
   if (c >= n_chunks) return;
@@ -617,7 +622,7 @@ __global__ __launch_bounds__(256) void k_tb_compose(IntervalTab iv, const int *c
 // HBM-bound kernel for a 2 Mb interval).
 __global__ __launch_bounds__(64) void k_tb_scan(IntervalTab iv, const int64_t *chunk0, int NP, const uint8_t *G,
                                                 const int *last_state, uint8_t *bstate, int64_t *paths) {
-  __builtin_amdgcn_s_setprio(3);      // latency kernel: issue ahead of co-resident throughput waves
+  __builtin_amdgcn_s_setprio(TEHMM_PRIO_HI);      // latency kernel: issue ahead of co-resident throughput waves
   __shared__ uint8_t rows[64 * 136];   // NP <= 132
   __shared__ uint8_t bst[64];
   const int id = blockIdx.x;
@@ -676,7 +681,7 @@ __global__ __launch_bounds__(64) void k_tb_group(IntervalTab iv, const int64_t *
 }
 __global__ __launch_bounds__(64) void k_tb_scan_top(IntervalTab iv, const int64_t *chunk0, int NP, const uint8_t *Gg,
                                                     const int *last_state, uint8_t *tstate, int64_t *paths) {
-  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(TEHMM_PRIO_HI);
   __shared__ uint8_t rows[64 * 136];
   __shared__ uint8_t bst[64];
   const int id = blockIdx.x, lane = threadIdx.x;
@@ -735,7 +740,7 @@ __global__ __launch_bounds__(256) void k_tb_fill(IntervalTab iv, int n_chunks, c
                                                  int TBW, const uint8_t *tb, const uint8_t *bstate, int64_t *paths) {
   extern __shared__ uint8_t tb_lds[];
   __shared__ uint8_t walked[4][TEHMM_TB_CHUNK];
-  __builtin_amdgcn_s_setprio(3);      // latency kernel: issue ahead of co-resident throughput waves
+  __builtin_amdgcn_s_setprio(TEHMM_PRIO_HI);      // latency kernel: issue ahead of co-resident throughput waves
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 4 + w;
   if (c >= n_chunks) return;

@@ -278,8 +278,8 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
   const int64_t cfirst = vc.first[id];
   // latency kernel next to throughput kernels of the other pipeline: ask the SIMD arbiter to issue this
   // workgroup's waves first (the chain wave above its helpers)
-  if (w == 0) __builtin_amdgcn_s_setprio(3);
-  else __builtin_amdgcn_s_setprio(2);
+  if (w == 0) __builtin_amdgcn_s_setprio(TEHMM_PRIO_HI);
+  else __builtin_amdgcn_s_setprio(TEHMM_PRIO_LO);
   __syncthreads();
   bool seen = false;     // leading-rows quirk state of the emission wave (_emission.pyx:73-80)
   if (w == 1)            // prologue: emission rows of block 0
@@ -747,8 +747,8 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
     *gen = 0;
   }
   const int64_t cfirst = fc.first[id];
-  if (w == 0) __builtin_amdgcn_s_setprio(3);       // see k_vit_fix
-  else __builtin_amdgcn_s_setprio(2);
+  if (w == 0) __builtin_amdgcn_s_setprio(TEHMM_PRIO_HI);       // see k_vit_fix
+  else __builtin_amdgcn_s_setprio(TEHMM_PRIO_LO);
   __syncthreads();
   bool seen = false;
   // blocks are aligned to multiples of 64 in both directions (the backward chain starts with the
