@@ -687,8 +687,10 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItem
   const double u = QUANT ? ldexp(1.0, e - 52) : 0.0;
   const double M = QUANT ? ldexp(1.5, e) : 0.0;          // fl(z + M) - M rounds z to the grid u
   const double half_u = 0.5 * u;
-  const double inv_u = QUANT ? ldexp(1.0, 52 - e) : 0.0;
-  const double wlim = QUANT ? -ldexp(1.0, e + 1) : -INFINITY;
+  // the arg-max extraction: xs + CM has exponent e for -2^e + 128 u < xs <= 63 u, i.e. its unit in the last place is
+  // u and the six low mantissa bits ARE xs / u mod 64 = 63 - (first arg-max); CM is a multiple of 64 u
+  const double CM = QUANT ? ldexp(1.0, e + 1) - ldexp(1.0, e - 45) : 0.0;          // 2^(e+1) - 128 u
+  const double wlim = QUANT ? -(ldexp(1.0, e) - ldexp(1.5, e - 45)) : -INFINITY;   // -(2^e - 192 u)
   const double zlim = QUANT ? ldexp(1.0, e - 1) : INFINITY;
   double W[NT];                                          // QUANT: 64 x (value - base); plain: value
 #pragma unroll
@@ -834,13 +836,13 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItem
           // tie <=> |b - R_u(b)| == u/2 for some state: tracked as a running minimum of the distance to
           // u/2 (one compare per step; 36 compares would each occupy a scalar mask).  Pads hold b = 0.
           tmin = fmin(tmin, fabs(fabs(bo - bq) - half_u));
-          const double m = xs[q];
-          const double k = m * inv_u;                          // m / u, an integer
-          const double r = k - 64.0 * floor(k * 0.015625);     // k mod 64 in [0, 63]
-          const int arg = 63 - (int)r;
-          // a dead state (m = -inf) makes r NaN: maxNum(NaN, -inf) puts -inf back without a branch
-          Wn[o] = fmax((m - r * u) + 64.0 * (RATIO ? bq + zq1[q] : bq), -INFINITY);
-          pw |= (uint32_t)(arg & 63) << (8 * q);
+          // (a dead state: xs = -inf stays -inf through all of this; a live state below the range makes the item
+          //  `bad` at the end of the step -- the new value is never above xs)
+          const double y = xs[q] + CM;                         // exact
+          const unsigned ylo = (unsigned)__double2loint(y);
+          const double m6 = __hiloint2double(__double2hiint(y), (int)(ylo & ~63u)) - CM;   // xs with the index bits cleared
+          Wn[o] = m6 + 64.0 * (RATIO ? bq + zq1[q] : bq);
+          pw |= (~ylo & 63u) << (8 * q);                        // 63 - (xs / u mod 64)
         } else {
           Wn[o] = xs[q] + bo;
         }
@@ -863,8 +865,9 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItem
 #pragma unroll
       for (int j = 0; j < NT; ++j) wl = fmin(wl, (j < NT - 8 || j < N) ? W[j] : INFINITY);
       if (!tie) pmin = fmin(pmin, wl * 0.015625 + base);
-      // W = 64 (value - base) + index bits must stay exactly representable: |W| < 2^53 u = 2^(e+1).  A state
-      // that falls further behind within a re-basing window (or dies) makes the item unusable.
+      // W = 64 (value - base) + index bits must stay inside the range of the arg-max extraction: |W| < 2^e - 192 u
+      // (half of what exact representability alone would allow).  A state that falls further behind within a
+      // re-basing window (or dies) makes the item unusable.
       bad = bad | (wl <= wlim);
     } else {
 #pragma unroll

@@ -37,7 +37,7 @@ namespace tehmm {
 #define TEHMM_SPEC_NONE (-2147483647 - 1)
 #ifndef TEHMM_SPEC_MIN_E
 // speculate only where |V| >= 2^15: the quantised pass keeps 64 x (offset from the best state) + 6 index bits
-// exact, so a state may fall 2^(e-5) = 1024 behind inside a re-basing window at e = 15 (items that exceed it
+// below 2^e, so a state may fall 2^(e-6) = 512 behind inside a re-basing window at e = 15 (items that exceed it
 // are left to the exact chain), and a chunk of 1024 positions still fits inside two binades
 #define TEHMM_SPEC_MIN_E 15
 #endif
