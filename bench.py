@@ -60,6 +60,21 @@ def launch_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def init_dist(dist, device):
+    """RCCL prints a version banner on STDOUT when its first communicator comes up; stdout is kept for the one
+    JSON line, so the banner goes to stderr."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group("nccl", device_id=device)
+        dist.barrier()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def gen_obs_torch(model, lens, seed, device):
     """Synthetic observations on the GPU (torch is plumbing here): state path made of geometric
     runs (sticky chain like the model's diagonal), symbols drawn from each state's per-track
@@ -131,7 +146,7 @@ def run_eval(args, rank, world, local_rank):
     use_dist = world > 1 or "RANK" in os.environ      # torchrun (even with one rank) -> RCCL path
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        init_dist(dist, device)
 
     mb = 100.0 if args.mb is None else args.mb
     model = synth.make_model(N_STATES, synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=0)
@@ -424,7 +439,7 @@ def run_estep(args, rank, world, local_rank):
     import torch.distributed as dist
     use_dist = world > 1 or "RANK" in os.environ
     if use_dist:
-        dist.init_process_group("nccl", device_id=device)
+        init_dist(dist, device)
     mb = 200.0 if args.mb is None else args.mb
     r = em_iterations(mb, args.steps, device, torch, dist if use_dist else None)
     if rank == 0:
