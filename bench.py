@@ -8,7 +8,13 @@ collective ("weak" scaling: every rank evaluates its own 100 Mb shard).
       --master-port P bench.py --gpus N ...                  # or under an external launcher
 
 One "step" = one tehmm_eval_batch(VITERBI | POSTERIOR) over the rank's whole batch of intervals,
-observations already resident in HBM, results left in HBM (paths int64 + posteriors f64).
+observations already resident in HBM, results left in HBM (paths int64 + posteriors f64).  Every timed
+step is a FIRST evaluation of its batch as far as derived data go (tehmm_batch_reset_cache drops the
+table-row index records of the fused passes): teHmmEval evaluates a batch once.  After the timing two
+intervals of the workload (the shortest and one of >= 1 Mb) are compared with the CPU oracle:
+`"verified": true` means paths and Viterbi scores bit-exact, posteriors and log-likelihood within 1e-6.
+`--scaling strong`: ONE config-3 interval list (the 9 alyrata scaffolds, 196 Mb, cut at synthetic mask
+gaps) LPT-sharded over the ranks (tehmm_amd.dist.lpt_shard) instead of 100 Mb per rank.
 `--mode estep` times BASELINE config 4 instead (Baum-Welch iterations: fused E-step per rank, ONE
 all-reduce of the packed statistics over RCCL, device M-step).  Rank 0 prints ONE JSON line.
 """
@@ -36,6 +42,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mode", choices=("eval", "estep"), default="eval")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --mb per GPU; strong: one 196 Mb whole-genome interval list sharded over the GPUs")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of two bench intervals")
     ap.add_argument("--mb", type=float, default=None, help="Mb of genome per GPU (eval: 100, estep: 200)")
     ap.add_argument("--min-kb", type=int, default=200, help="shortest interval (kb)")
     ap.add_argument("--max-kb", type=int, default=2000, help="longest interval (kb)")
@@ -126,6 +135,49 @@ def cpu_baseline(model, n_threads, per_interval, n_iv, seed=123):
                       % (n_iv, per_interval, n_threads, dt)}
 
 
+# data/alyrata.bed of the reference: the 9 scaffolds of BASELINE configs[2] (sum 196 089 052)
+ALYRATA_SCAFFOLDS = (33132539, 19320864, 24464547, 23328337, 21221946, 25113588, 24649197, 22951293, 1906741)
+
+
+def genome_intervals(min_kb, max_kb, seed=1000):
+    """every scaffold cut at synthetic mask gaps every U(min_kb, max_kb)."""
+    from tehmm_amd import synth
+    out = []
+    for i, L in enumerate(ALYRATA_SCAFFOLDS):
+        out.extend(int(x) for x in synth.interval_lengths(L, min_kb * 1000, max_kb * 1000, seed=seed + i))
+    return np.asarray(out, dtype=np.int64)
+
+
+def verify_intervals(model, hb, obs, offs, res, n_threads=2):
+    """Oracle check of the bench workload itself: the shortest interval and the shortest one of >= 1 Mb (if
+    any), results of the LAST timed step against oracle.eval_batch on the same observations."""
+    from oracle import oracle
+    lens = np.diff(offs)
+    pick = [int(np.argmin(lens))]
+    big = np.where(lens >= 1_000_000)[0]
+    if len(big):
+        pick.append(int(big[np.argmin(lens[big])]))
+    pick = sorted(set(pick))
+    sub_obs = np.concatenate([obs[int(offs[i]):int(offs[i + 1])].cpu().numpy() for i in pick], axis=0)
+    sub_offs = np.concatenate([[0], np.cumsum(lens[pick])]).astype(np.int64)
+    t0 = time.perf_counter()
+    p_o, vlp_o, flp_o, post_o = oracle.eval_batch(sub_obs, sub_offs, model.log_probs, model.log_startprob,
+                                                  model.log_transmat, 1.0, None, want_post=True,
+                                                  n_threads=n_threads)
+    ok, worst = True, 0.0
+    for j, i in enumerate(pick):
+        a, b = int(offs[i]), int(offs[i + 1])
+        sl = slice(int(sub_offs[j]), int(sub_offs[j + 1]))
+        ok &= bool(np.array_equal(hb.paths(a, b), p_o[sl]))
+        ok &= bool(res["viterbi_logprob"][i] == vlp_o[j])
+        ok &= bool(abs(res["forward_logprob"][i] - flp_o[j]) <= 1e-6 * abs(flp_o[j]))
+        rel = float(np.max(np.abs(hb.posteriors(model.n_states, a, b) - post_o[sl]) / post_o[sl]))
+        worst = max(worst, rel)
+        ok &= rel <= 1e-6
+    return {"verified": bool(ok), "verified_intervals": [int(lens[i]) for i in pick],
+            "posterior_max_rel_err": worst, "verify_s": time.perf_counter() - t0}
+
+
 def time_eval(hm, hb, torch, steps=1, **kw):
     hm.eval(hb, **kw)                        # warm-up (allocates result buffers / workspaces)
     torch.cuda.synchronize()
@@ -150,8 +202,18 @@ def run_eval(args, rank, world, local_rank):
 
     mb = 100.0 if args.mb is None else args.mb
     model = synth.make_model(N_STATES, synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=0)
-    total = int(mb * 1e6)
-    lens = synth.interval_lengths(total, args.min_kb * 1000, args.max_kb * 1000, seed=1000 + rank)
+    strong = args.scaling == "strong"
+    if strong:
+        # ONE whole-genome interval list, identical on every rank; this rank evaluates its LPT shard
+        from tehmm_amd import dist as tdist
+        all_lens = genome_intervals(args.min_kb, args.max_kb)
+        shard = tdist.lpt_shard(all_lens, world)[rank]
+        lens = all_lens[shard]
+        job_total = int(all_lens.sum())
+    else:
+        lens = synth.interval_lengths(int(mb * 1e6), args.min_kb * 1000, args.max_kb * 1000, seed=1000 + rank)
+        job_total = int(mb * 1e6) * world
+    total = int(lens.sum())
     offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     obs = gen_obs_torch(model, lens, seed=17 + rank, device=device)
     torch.cuda.synchronize()
@@ -170,10 +232,12 @@ def run_eval(args, rank, world, local_rank):
     for _ in range(args.warmup):
         hm.eval(hb, viterbi=True, posterior=True)
     kt = {}
+    res = None
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        hm.eval(hb, viterbi=True, posterior=True)
+        hb.reset_cache()                          # every timed step is a first evaluation of its batch
+        res = hm.eval(hb, viterbi=True, posterior=True)
         for name, ms in hb.timing().items():      # HIP events on the library's own streams
             if not name.startswith("count:"):
                 kt.setdefault(name, []).append(ms)
@@ -185,16 +249,21 @@ def run_eval(args, rank, world, local_rank):
         dt = float(tt.item())
         # the "trivial gather" of the per-interval scores (north_star): exercised once, outside the timing
         from tehmm_amd import dist as tdist
-        res = hm.eval(hb, viterbi=True, posterior=False)
-        all_lens = [None] * world
-        dist.all_gather_object(all_lens, [int(x) for x in lens])
-        flat = [x for r in all_lens for x in r]
-        first = sum(len(r) for r in all_lens[:rank])
-        tdist.gather_interval_scalars(np.arange(first, first + len(lens)), res["viterbi_logprob"], len(flat))
+        if strong:
+            tdist.gather_interval_scalars(shard, res["viterbi_logprob"], len(all_lens))
+        else:
+            rank_lens = [None] * world
+            dist.all_gather_object(rank_lens, [int(x) for x in lens])
+            flat = [x for r in rank_lens for x in r]
+            first = sum(len(r) for r in rank_lens[:rank])
+            tdist.gather_interval_scalars(np.arange(first, first + len(lens)), res["viterbi_logprob"], len(flat))
+    verdict = None
+    if rank == 0 and not args.no_verify and res is not None:
+        verdict = verify_intervals(model, hb, obs, offs, res)
 
     if rank == 0:
         K, N = model.n_tracks, model.n_states
-        pos_per_step = float(total) * world
+        pos_per_step = float(job_total)
         value = pos_per_step * args.steps / dt
         step_s = dt / args.steps
         kavg = {k: float(np.mean(v)) for k, v in kt.items()}
@@ -203,7 +272,7 @@ def run_eval(args, rank, world, local_rank):
         # path out) + 8 N (posterior row out); roofline.achieved = that x the positions one step (one
         # tehmm_eval_batch launch sequence) processes / the step's duration.
         alg_pos = K + 8 + 8 * N
-        achieved = alg_pos * float(total) / step_s / 1e9
+        achieved = alg_pos * float(total) / step_s / 1e9        # this rank's GPU: its positions / the step's duration
         # per-stage view (stage durations are HIP events on the streams the kernels ran on): algorithmic
         # bytes each stage is responsible for, fp64 operations, measured HBM traffic (rocprofv3 --pmc)
         alg = {"viterbi": 8, "viterbi_speculate": K, "traceback": 8, "emission_rows": K,
@@ -227,12 +296,17 @@ def run_eval(args, rank, world, local_rank):
             "metric": "genome positions/sec (Viterbi+posterior), 35 states x 10 tracks",
             "value": value, "unit": "positions/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": step_s * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "teHmmEval Viterbi+posterior, 35 states, 10 tracks (8 multinomial "
-                                   "+ 2 gaussian/250 bins), %.0f Mb per GPU in %d intervals of "
-                                   "%d-%d kb (config-3 geometry), obs resident in HBM"
-                                   % (mb, len(lens), args.min_kb, args.max_kb),
+                                   "+ 2 gaussian/250 bins), %s in intervals of %d-%d kb (config-3 geometry), "
+                                   "obs resident in HBM, every step a first evaluation (index records rebuilt)"
+                                   % ("ONE %.0f Mb whole-genome interval list (9 alyrata scaffolds, %d intervals) "
+                                      "LPT-sharded over the GPUs" % (job_total / 1e6, len(all_lens)) if strong
+                                      else "%.0f Mb per GPU in %d intervals" % (mb, len(lens)),
+                                      args.min_kb, args.max_kb),
+                       "arithmetic": "f64 arithmetic throughout; alpha' rows kept as f32 between the forward and "
+                                     "backward passes (posteriors agree with the reference to ~1e-7, bar 1e-6)",
                        "positions_per_gpu": total, "intervals_per_gpu": int(len(lens)),
                        "parallelism": "intervals sharded over %d GPU(s), no collective" % world},
             "roofline": {"bound": "hbm", "kernel": "tehmm_eval_batch: Viterbi + posterior over the batch (SURVEY 8d)",
@@ -252,6 +326,8 @@ def run_eval(args, rank, world, local_rank):
                                                 for k in kavg if k in flop}}},
             "kernel_ms": kavg,
         }
+        if verdict is not None:
+            out.update(verdict)
         if world == 1 and not args.no_extra:
             out["extra"] = extras(args, model, hm, hb, obs, offs, lens, device, torch, mk_model)
         if world == 1 and not args.no_cpu_baseline:

@@ -120,6 +120,10 @@ int tehmm_batch_create(int n_intervals, const int64_t *offsets, int K, const uin
                        const double *segRatios, int obs_on_device, tehmm_batch_t **out);
 int tehmm_batch_destroy(tehmm_batch_t *batch);
 int64_t tehmm_batch_total(const tehmm_batch_t *batch);
+/* Forgets what earlier evaluations derived from the batch's observations for a model (the table-row index
+ * records of the fused posterior passes): the next call pays for them again, as the first evaluation of a
+ * fresh batch does.  bench.py calls it before every timed step -- teHmmEval evaluates a batch once. */
+int tehmm_batch_reset_cache(tehmm_batch_t *batch);
 
 /* Flags for tehmm_eval_batch. */
 #define TEHMM_EVAL_VITERBI 1   /* BaseHMM.decode -> _decode_viterbi (basehmm.py:301-330, 361-396) */
@@ -177,6 +181,9 @@ int tehmm_stats_alloc(const tehmm_model_t *model, double **dev_stats);   /* zero
 int tehmm_stats_zero(const tehmm_model_t *model, double *dev_stats);
 int tehmm_stats_free(double *dev_stats);
 int tehmm_stats_head(const double *dev_stats, double *logprob_sum, double *n_sequences);
+/* Copies the whole buffer device -> host (to_device = 0) or host -> device (to_device = 1): how a process group
+ * whose backend cannot see device memory (gloo) sums the statistics of its ranks. */
+int tehmm_stats_copy(const tehmm_model_t *model, double *dev_stats, double *host_buf, int to_device);
 /* tehmm_estep_batch with the statistics ADDED into dev_stats (a device pointer: from tehmm_stats_alloc
  * or e.g. a torch tensor that RCCL will all-reduce). */
 int tehmm_estep_batch_device(tehmm_model_t *model, tehmm_batch_t *batch, int use_ratios, double *dev_stats,

@@ -44,6 +44,7 @@ SIGNATURES = {
     "tehmm_stats_zero": (c_int, [vp, vp]),
     "tehmm_stats_free": (c_int, [vp]),
     "tehmm_stats_head": (c_int, [vp, f64p, f64p]),
+    "tehmm_stats_copy": (c_int, [vp, vp, f64p, c_int]),
     "tehmm_estep_batch_device": (c_int, [vp, vp, c_int, vp, f64p]),
     "tehmm_model_mstep": (c_int, [vp, vp, c_int, c_int, c_int, c_dbl, c_dbl, c_dbl, c_int, i32p, f64p, c_dbl,
                                   f64p]),
@@ -61,6 +62,7 @@ SIGNATURES = {
     "tehmm_batch_create": (c_int, [c_int, i64p, c_int, vp, vp, c_int, ctypes.POINTER(vp)]),
     "tehmm_batch_destroy": (c_int, [vp]),
     "tehmm_batch_total": (c_i64, [vp]),
+    "tehmm_batch_reset_cache": (c_int, [vp]),
     "tehmm_eval_batch": (c_int, [vp, vp, c_int, f64p, f64p]),
     "tehmm_batch_get_paths": (c_int, [vp, c_i64, c_i64, i64p]),
     "tehmm_batch_get_posteriors": (c_int, [vp, c_i64, c_i64, f64p]),

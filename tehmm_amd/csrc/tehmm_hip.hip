@@ -663,6 +663,14 @@ int tehmm_batch_destroy(tehmm_batch_t *b) {
 
 int64_t tehmm_batch_total(const tehmm_batch_t *b) { return b ? b->total : 0; }
 
+int tehmm_batch_reset_cache(tehmm_batch_t *b) {
+  if (!b) return fail(TEHMM_ERR_ARG, "tehmm_batch_reset_cache: NULL handle");
+  b->lw.rix_model = 0;
+  b->lw.rix_L = 0;
+  b->lw.rix_Wu = 0;
+  return TEHMM_OK;
+}
+
 static void fill_tabs(const tehmm_model *m, const tehmm_batch *b, IntervalTab &iv, EmisTab &em,
                       bool emis_ratios) {
   iv.order = b->d_order.p;
@@ -1278,8 +1286,8 @@ static void launch_fb_lane(tehmm_batch *b, const tehmm_model *m, const IntervalT
 // chain (alpha' rows final) -> backward lane pass writing the posterior rows -> backward links / runs ->
 // [ev_mid] -> backward exact chain (posterior rows of its exact blocks).  ev_fwd: end of the forward half.
 template <int NT>
-static void launch_fused_fb(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em_in,
-                            const FbChunks &fc, int Wu, hipStream_t st, hipEvent_t ev_fwd, hipEvent_t ev_mid) {
+static int launch_fused_fb(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em_in,
+                           const FbChunks &fc, int Wu, hipStream_t st, hipEvent_t ev_fwd, hipEvent_t ev_mid) {
   LaneWork &lw = b->lw;
   const LaneGeom lg = lane_geom(lw);
   const dim3 gridm((unsigned)lw.n_groups);           // 4 tiles of 16 items per 256-thread block = one group
@@ -1321,7 +1329,8 @@ static void launch_fused_fb(tehmm_batch *b, const tehmm_model *m, const Interval
   fo.NB = (lw.L + 2 * Wu + fo.SB - 1) / fo.SB;
   if (!lw.rix.p || lw.rix_model != m->uid || lw.rix_L != lw.L || lw.rix_Wu != Wu) {
     const size_t words = (size_t)lw.n_groups * 4 * fo.NB * TEHMM_FUSED_BLKW * 16;
-    (void)lw.rix.ensure(words + 16);
+    lw.rix_model = 0;                                   // (the key is set once the records exist)
+    HIPCHK(lw.rix.ensure(words + 16));
     hipLaunchKernelGGL(k_fused_rowindex, dim3(grid_for((int64_t)lw.n_groups * 4 * fo.NB * fo.SB * 16, 256, 1 << 20)),
                        dim3(256), 0, st, iv, lg, fo, (const uint8_t *)b->obs.p, lw.rix.p);
     lw.rix_model = m->uid;
@@ -1379,6 +1388,7 @@ static void launch_fused_fb(tehmm_batch *b, const tehmm_model *m, const Interval
                      m->lt.p, m->pi.p, (const double *)nullptr, (double *)nullptr, b->fwd_lp.p, b->dead.p,
                      (double *)nullptr, (int *)nullptr, 1, b->sw.stats.p, lg, (const int *)lw.ok_b.p,
                      (const double *)lw.chk.p, b->post.p, lw.AL32.p, (const double *)nullptr);
+  return TEHMM_OK;
 }
 
 template <int NT>
@@ -1602,9 +1612,11 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       (void)hipMemsetAsync(b->dead.p, 0, (size_t)(b->n + 1) * sizeof(int), st);
       (void)hipMemsetAsync(sw.stats.p + 2, 0, 4 * sizeof(int), st);
       if (fused_fb) {
-#define CALL(NT_) launch_fused_fb<NT_>(b, m, iv, em, fc, WuF, st, b->ev[eP + 3], b->ev[eP + 1])
+        int rcf = TEHMM_OK;
+#define CALL(NT_) rcf = launch_fused_fb<NT_>(b, m, iv, em, fc, WuF, st, b->ev[eP + 3], b->ev[eP + 1])
         TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
+        if (rcf) return rcf;
       } else {
 #define CALL(NT_) launch_fb_lane<NT_>(b, m, iv, em, fc, WuF, st, b->ev[eP + 3])
         TEHMM_NT_DISPATCH(m->NP, CALL)

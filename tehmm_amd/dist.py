@@ -34,6 +34,17 @@ def _dist():
     return dist
 
 
+def world_rank():
+    """(world size, rank) of the default process group; (1, 0) without one."""
+    try:
+        dist = _dist()
+    except ImportError:
+        return 1, 0
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1, 0
+    return dist.get_world_size(), dist.get_rank()
+
+
 def _device_for_backend():
     import torch
     dist = _dist()
@@ -74,13 +85,34 @@ def allreduce_stats(stats, logprob):
 def allreduce_device_stats(stats):
     """The one collective of an EM iteration, in place on the device buffer of the raw statistics
     (engine.DeviceStats).  nccl backend: RCCL all-reduce of the buffer's torch tensor over xGMI;
-    any other backend (gloo in the CPU tests) cannot see device memory and is refused."""
+    any other backend (gloo: the two-rank tests) cannot see device memory, so the buffer is staged
+    through the host (0.2 MB at N = 35, K = 10)."""
+    import torch
     dist = _dist()
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
-    if stats.tensor is None:
-        raise RuntimeError("device-resident statistics need the nccl backend for the all-reduce")
-    dist.all_reduce(stats.tensor, op=dist.ReduceOp.SUM)
+    if stats.tensor is not None and dist.get_backend() == "nccl":
+        dist.all_reduce(stats.tensor, op=dist.ReduceOp.SUM)
+        return
+    t = torch.from_numpy(stats.to_host())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    stats.from_host(t.numpy())
+
+
+def allgather_values(local_idx, local_values, n_total):
+    """gather_interval_scalars under a name the EM driver reads better with."""
+    return gather_interval_scalars(local_idx, local_values, n_total)
+
+
+def all_agree(flag):
+    """True iff `flag` is true on EVERY rank (one all-reduce; trivially `flag` without a process group)."""
+    import torch
+    dist = _dist()
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=_device_for_backend())
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
 
 
 def gather_interval_scalars(local_idx, local_values, n_total, lengths=None):
@@ -124,23 +156,43 @@ def gather_paths(local_idx, local_paths, lengths):
             out[int(i)] = np.asarray(p, dtype=np.int64)
         return out
     world = dist.get_world_size()
-    shards = lpt_shard(lengths, world)
-    sizes = [int(lengths[s].sum()) for s in shards]
-    cap = max(max(sizes), 1)
     dev = _device_for_backend()
+    local_idx = np.asarray(local_idx, dtype=np.int64)
+    if len(local_idx) != len(local_paths):
+        raise ValueError("gather_paths: %d indices for %d paths" % (len(local_idx), len(local_paths)))
+    for i, p in zip(local_idx, local_paths):
+        if len(p) != int(lengths[i]):
+            raise ValueError("gather_paths: path of interval %d has %d states, the interval %d rows"
+                             % (int(i), len(p), int(lengths[i])))
+    # which intervals every rank holds, in the order it sends them (any sharding, not only lpt_shard's)
+    cnt = torch.tensor([len(local_idx)], dtype=torch.int64, device=dev)
+    cmax = cnt.clone()
+    dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+    icap = max(int(cmax.item()), 1)
+    ibuf = np.full(icap, -1, dtype=np.int64)
+    ibuf[:len(local_idx)] = local_idx
+    isend = torch.from_numpy(ibuf).to(dev)
+    irecv = torch.empty(world * icap, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(irecv, isend)
+    held = irecv.cpu().numpy().reshape(world, icap)
+    sizes = [int(lengths[h[h >= 0]].sum()) for h in held]
+    cap = max(max(sizes), 1)
     mine = np.zeros(cap, dtype=np.uint8)
     if len(local_paths):
         cat = np.concatenate([np.asarray(p) for p in local_paths]) if len(local_paths) > 1 else np.asarray(local_paths[0])
-        assert cat.size == 0 or int(cat.max()) < 256
+        if cat.size and (int(cat.max()) >= 256 or int(cat.min()) < 0):
+            raise ValueError("gather_paths: states must fit a byte")
         mine[:cat.size] = cat.astype(np.uint8)
     send = torch.from_numpy(mine).to(dev)
     recv = torch.empty(world * cap, dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(recv, send)
     recv = recv.cpu().numpy().reshape(world, cap)
     out = [None] * n
-    for r, shard in enumerate(shards):
+    for r in range(world):
         o = 0
-        for i in shard:
+        for i in held[r][held[r] >= 0]:
+            if out[int(i)] is not None:
+                raise ValueError("gather_paths: interval %d is held by more than one rank" % int(i))
             out[int(i)] = recv[r, o:o + int(lengths[i])].astype(np.int64)
             o += int(lengths[i])
     return out

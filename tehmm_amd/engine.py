@@ -63,7 +63,7 @@ class HipModel(object):
         """MultitrackHmm._do_mstep on the device; gauss = (track indices, values [n][S], uniform mix) or
         None.  Returns the gaussian (mu, sigma) table [n][N][2] or None."""
         n_g, gt, gv, mix, gp = 0, None, None, 0.1, None
-        if gauss is not None:
+        if gauss is not None and do_emission:     # (the gaussian refit is part of the emission update only)
             gt = np.ascontiguousarray(gauss[0], dtype=np.int32)
             gv = np.ascontiguousarray(gauss[1], dtype=np.float64)
             mix = float(gauss[2])
@@ -121,6 +121,16 @@ class DeviceStats(object):
 
     def zero(self):
         _lib.check(_lib.load().tehmm_stats_zero(self.model._h, self.ptr), "tehmm_stats_zero")
+
+    def to_host(self):
+        out = np.zeros(self.size, dtype=np.float64)
+        _lib.check(_lib.load().tehmm_stats_copy(self.model._h, self.ptr, ptr(out, f64p), 0), "tehmm_stats_copy")
+        return out
+
+    def from_host(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.float64)
+        assert buf.shape == (self.size,)
+        _lib.check(_lib.load().tehmm_stats_copy(self.model._h, self.ptr, ptr(buf, f64p), 1), "tehmm_stats_copy")
 
     def head(self):
         lp, n = ctypes.c_double(0.0), ctypes.c_double(0.0)
@@ -184,6 +194,10 @@ class HipBatch(object):
             self._h = None
 
     __del__ = close
+
+    def reset_cache(self):
+        """Forget what earlier evaluations derived from the observations (tehmm_batch_reset_cache)."""
+        _lib.check(_lib.load().tehmm_batch_reset_cache(self._h), "tehmm_batch_reset_cache")
 
     def paths(self, row0=0, row1=None):
         row1 = self.total if row1 is None else row1

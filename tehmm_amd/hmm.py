@@ -150,6 +150,28 @@ class MultitrackHmm(BaseHMM):
     def getStartProbs(self):
         return self.startprob_
 
+    def getNumFreeParameters(self):
+        """Number of free, learnable parameters (hmm.py:490-520; feeds the BIC of teHmmEval.py:216-234)."""
+        if self.forceUserTrans is not None or self.forceUserStart is not None or \
+                self.forceUserEmissions is not None:
+            raise RuntimeError("hmm.getNumFreeParamaters() does not yet support forceUsers{Trans,Start,Emissions}"
+                               " functionality.  ie only works for completely unsupervised learining")
+        numParams = 0
+        numStates = self.emissionModel.getNumStates()
+        if self.fixTrans is False:
+            numParams += numStates * (numStates - 1) - self.numZeroInitEdges
+        if self.fixStart is False:
+            numParams += numStates - 1 - self.numZeroInitStarts
+        if self.fixEmission is False:
+            for track in self.trackList:
+                trackNo = track.getNumber()
+                if track.getDist() == "gaussian":
+                    numTrackParams = 2
+                else:
+                    numTrackParams = self.emissionModel.getNumSymbolsPerTrack()[trackNo] - 1
+                numParams += numStates * numTrackParams
+        return numParams
+
     def validate(self):
         assert len(self.startprob_) == self.emissionModel.getNumStates()
         assert not np.isnan(self.startprob_.any())
@@ -384,26 +406,40 @@ class MultitrackHmm(BaseHMM):
             return False
         if type(em) is IndependentMultinomialAndGaussianEmissionModel and self.trackList is None:
             return False
+        # (decided on the GLOBAL table list, which every rank passes alike: no rank may leave the others alone
+        #  in the per-iteration all-reduce)
         return em.zeroAsMissingData is True and self.n_components < 64 and len(obs) > 0 and self._can_fuse(obs)
 
     def _fit_device(self, tables):
         """BaseHMM.fit (basehmm.py:475-541) with the observations, the sufficient statistics and the
         parameters resident on the device: per iteration one fused E-step per batch (statistics ADDED
-        into one flat device buffer -- all-reduced over the ranks when torch.distributed is up), the
-        convergence test on the returned log-likelihood, and tehmm_model_mstep.  The host model is
-        refreshed at the end (every iteration with maxProb, whose bookkeeping deep-copies the model)."""
+        into one flat device buffer), the convergence test on the returned log-likelihood, and
+        tehmm_model_mstep.  The host model is refreshed at the end (every iteration with maxProb, whose
+        bookkeeping deep-copies the model).
+
+        With torch.distributed initialised every rank passes the SAME table list: the tables are
+        LPT-sharded here (dist.lpt_shard), each rank keeps only its shard on its GPU, and the ranks meet in
+        exactly one all-reduce of the statistics buffer per iteration plus one all-gather of the
+        per-sequence log-likelihoods, so that the convergence test, the --maxProb bookkeeping (hmm.py:690-711)
+        and the M-step see global values and take identical decisions everywhere.  A rank whose shard is
+        empty still takes part, with zero statistics."""
         from . import dist as tdist
         from .engine import DeviceStats, HipBatch
         if self.algorithm not in ("viterbi", "map"):
             self._algorithm = "viterbi"
         self._init(tables, self.init_params)
-        arrays = [t.getNumPyArray() if isinstance(t, TrackTable) else np.ascontiguousarray(t)
-                  for t in tables]
-        ratios = [self.emissionModel.getSegmentRatios(t) for t in tables]
+        world, rank = tdist.world_rank()
+        n_seq = len(tables)
+        mine = list(range(n_seq))
+        if world > 1:
+            mine = [int(i) for i in tdist.lpt_shard([len(t) for t in tables], world)[rank]]
+        arrays = {i: (tables[i].getNumPyArray() if isinstance(tables[i], TrackTable)
+                      else np.ascontiguousarray(tables[i])) for i in mine}
+        ratios = {i: self.emissionModel.getSegmentRatios(tables[i]) for i in mine}
         hm = self._device_model()
         batches = []
         for has_r in (True, False):
-            idx = [i for i, r in enumerate(ratios) if (r is not None) == has_r]
+            idx = [i for i in mine if (ratios[i] is not None) == has_r]
             if not idx:
                 continue
             lens = np.asarray([arrays[i].shape[0] for i in idx], dtype=np.int64)
@@ -417,13 +453,15 @@ class MultitrackHmm(BaseHMM):
         try:
             for i in range(copy.deepcopy(self.n_iter)):
                 stats.zero()
-                seq_lp = np.zeros(len(tables))
+                loc_idx, loc_lp = [], []
                 for has_r, idx, hb in batches:
                     hm.estep_device(hb, has_r, stats)
-                    seq_lp[idx] = hb.interval_logprobs()
+                    loc_idx.extend(idx)
+                    loc_lp.extend(hb.interval_logprobs())
+                seq_lp = tdist.gather_interval_scalars(loc_idx, loc_lp, n_seq)
                 if self.maxProb is True:
                     self._pull_params(hm)
-                for lp in seq_lp:
+                for lp in seq_lp:                      # global values, global sequence order: same on every rank
                     self._note_forward_logprob(float(lp))
                 tdist.allreduce_device_stats(stats)
                 curr_logprob = stats.head()[0]
@@ -433,11 +471,12 @@ class MultitrackHmm(BaseHMM):
                     break
                 if i == self.n_iter - 1:
                     break
-                gp = hm.mstep(stats, "s" in self.params, "t" in self.params, "e" in self.params,
+                do_e = "e" in self.params
+                gp = hm.mstep(stats, "s" in self.params, "t" in self.params, do_e,
                               1.0 if self.startprob_prior is None else self.startprob_prior,
                               1.0 if self.transmat_prior is None else self.transmat_prior,
                               self.emissionModel.fudge, gauss)
-                if gp is not None:
+                if gp is not None and do_e:
                     for g, k in enumerate(gauss[0]):
                         self.emissionModel.gaussParams[k] = gp[g]
                 self.current_iteration += 1

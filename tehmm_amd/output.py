@@ -51,3 +51,29 @@ def statesToBed(trackTable, states, bedPath=None, posteriorSums=None, posteriors
         _write(bedPath, append, chrom, starts, ends, states=states, names=stateNames)
     if posteriorSums is not None and posteriorsPath is not None:
         _write(posteriorsPath, append, chrom, starts, ends, values=np.roll(np.asarray(posteriorSums), 1))
+
+
+def bic(model, totalScore, totalDatapoints):
+    """Bayesian information criterion as teHmmEval.py:216-234 writes it: -2 lnL + k (ln n + ln 2 pi), with
+    lnL the summed Viterbi score, n = rows x tracks and k = model.getNumFreeParameters() (0 when the
+    model cannot say: the reference swallows the exception).  Returns (bic, k)."""
+    lnL = float(totalScore)
+    try:
+        k = float(model.getNumFreeParameters())
+    except Exception:
+        k = 0.0
+    n = float(totalDatapoints)
+    return -2.0 * lnL + k * (np.log(n) + np.log(2 * np.pi)), k
+
+
+def writeBic(path, model, totalScore, totalDatapoints):
+    """The two-line --bic file of teHmmEval.py:216-234."""
+    value, k = bic(model, totalScore, totalDatapoints)
+    em = model.getEmissionModel()
+    with open(path, "w") as f:
+        f.write("%f\n" % value)
+        f.write("# = -2.0 * lnL + k * (lnN + ln(2 * np.pi))\n"
+                "# where lnL=%f  k=%d (%d states)  N=%d (%d obs * %d tracks)  lnN=%f\n" % (
+                    float(totalScore), int(k), em.getNumStates(), int(totalDatapoints),
+                    totalDatapoints / em.getNumTracks(), em.getNumTracks(), np.log(float(totalDatapoints))))
+    return value
