@@ -1,0 +1,360 @@
+// tehmm_estep.hip.h -- the Baum-Welch E-step reductions on top of the chunk-parallel fused passes (round 3).
+//
+// Reference: BaseHMM.fit's per-sequence loop (basehmm.py:504-523) + MultitrackHmm._accumulate_sufficient_statistics
+// (hmm.py:545-574) + _hmm._log_sum_lneta (_hmm.pyx:62-117) + _emission.fastAccumulateStats (_emission.pyx:146-190).
+//
+// Round 2 ran the E-step as ONE sequential forward / backward chain per interval (k_fb_coop, fp64 alpha, beta
+// and w rows through HBM: 840 bytes per position) and a lane = state accumulation kernel that issued 36 DPP
+// FMAs and up to 70 fp64 global atomics per position.  Here the posterior pipeline of tehmm_fused.hip.h does the
+// forward / backward work chunk-parallel (k_fused_fwd, k_fused_bwd<ESTEP>, the exact chains k_fb_fix for what
+// the speculation cannot vouch for), leaving three FLOAT rows per position in the alpha' layout (al32_index):
+//     alpha'_t                      (k_fused_fwd / forward chain)
+//     gamma_t = alpha'_t beta_t / G_t                         -> start, emission histograms
+//     wz_t    = w_{t+1} scale_t / G_t                         -> xi_t(i, j) = alpha'_t[i] A[i][j] wz_t[j]
+// Rows are WRITTEN (the exact chain overwrites what the speculation left), never accumulated in place, so every
+// position is counted once whatever the chains decided; k_estep_reduce then reads each row once per track group:
+//   * C[i][j] += sum_t alpha'_t[i] wz_t[j] is a GEMM over the positions (M = N = states, K = positions) and runs
+//     on the fp64 matrix cores: v_mfma_f64_16x16x4 contracts four ITEMS of a 16-item tile per instruction, the
+//     16 rows / columns of an operand are states.  The alpha' layout keeps, for a state pair-quad, 16 items x
+//     (state, state + 4) as consecutive float2, so operand (row tile, 4 items) is one 8-byte load per lane and
+//     row tiles are the state sets {8 p + kq} and {8 p + 4 + kq} (p = 4 q .. 4 q + 3, kq = 0 .. 3) -- any
+//     bijection rows <-> states is legal as long as the accumulators are written back through it;
+//   * the emission histograms obs[k][sym][j] += gamma_t[j]: tracks with FEW symbols are one more product on the
+//     matrix cores (one-hot rows x gamma rows, k_estep_hist_mfma); tracks with many symbols (the 250-bin gaussian
+//     tracks) are privatised in LDS in fp64 (ds_add_f64, lane = (item, state quarter), k_estep_hist_lds), grouped
+//     so that a group's rows fit the 160 KB of a CU; one flush per workgroup instead of per-position global
+//     atomics (round 2: 23 of 62 ms).  First version: everything through LDS atomics, 36 of its 40 ms per 50 Mb
+//     were ds_add_f64 at ~1 lane per cycle;
+//   * start += gamma_0 of every interval.
+// Tolerance: the rows are floats (relative 6e-8 each), the sums fp64: statistics agree with the reference to
+// ~1e-7 (bar 1e-6, asserted in tests/test_gpu_r3.py).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "tehmm_fused.hip.h"
+
+namespace tehmm {
+
+// Track partition of the reduction (built on the host, estep_build_groups):
+//   * LDS groups: tracks with many symbols, histograms privatised in LDS (ds_add_f64 costs ~55 cycles per wave
+//     instruction whatever the addresses -- measured: 2.3 ms per track and 50 Mb --, i.e. ~500 LDS cycles per track,
+//     tile and step), at most `cap` rows per group;
+//   * row-tile groups: tracks with few symbols go through the matrix cores instead (16 (track, symbol) rows per
+//     tile, 12 matrix instructions = 192 CU cycles per row tile, tile and step: cheaper below ~2.6 row tiles per
+//     track), at most TEHMM_ESTEP_RTG row tiles per group.
+#define TEHMM_ESTEP_MAXRT 64          // row tiles of the one-hot reduction (16 rows each)
+struct EstepGroups {
+  int n_lds;                           // LDS groups (grid.y of k_estep_hist_lds)
+  int first[TEHMM_MAX_TRACKS + 1];     // LDS group g owns the slots [first[g], first[g + 1])
+  int rows[TEHMM_MAX_TRACKS];          // LDS group -> rows of its histogram
+  int info[TEHMM_MAX_TRACKS];          // slot -> observation column | rows of the track << 7 | first LDS row << 16
+  int gbase[TEHMM_MAX_TRACKS];         // slot -> first row of the track in the global statistics table
+  int n_rt;                            // row tiles of the one-hot reduction
+  int rt_info[TEHMM_ESTEP_MAXRT * 16]; // row -> observation column | symbol << 8, or -1 (padding row)
+  int rt_grow[TEHMM_ESTEP_MAXRT * 16]; // row -> row of the global statistics table
+};
+
+template <int NT>
+struct EstepGeom {
+  static constexpr int KS = NT / 4;
+  static constexpr int P = al32_pairs(NT);               // float2 per lane and row
+  static constexpr int PQ = (P + 3) / 4;                 // pair quads
+  // state tiles (q, h): states 8 (4 q + pp) + 4 h + kq; a tile exists when its first state does
+  static constexpr int NTILE = 2 * PQ - ((32 * (PQ - 1) + 4 < NT) ? 0 : 1);
+  static constexpr int RTG = 24 / NTILE;                 // row tiles per workgroup role of the one-hot reduction
+  static __host__ __device__ constexpr int state(int tile, int m) {
+    return 8 * (4 * (tile >> 1) + (m >> 2)) + 4 * (tile & 1) + (m & 3);
+  }
+};
+
+__device__ __forceinline__ void estep_atomic_add(double *p, double v) { unsafeAtomicAdd(p, v); }
+
+// What every reduction kernel knows about the 16-item tile a wave works on.
+struct EstepTile {
+  int ns, nsmax;            // positions of this lane's item / of the longest item of the tile
+  int64_t t0;               // first position of this lane's item
+  const uint8_t *orow;      // observation row of (this lane's item, position 0)
+  int64_t tb2;              // float2 index of (position 0, pair 0) of the tile; one position further = 256 P float2
+};
+template <int NT>
+__device__ __forceinline__ EstepTile estep_tile(const IntervalTab &iv, const LaneGeom &lg, int64_t tile, int i16, int KP,
+                                                const uint8_t *obs) {
+  EstepTile tc;
+  const int64_t item = tile * 16 + i16;
+  const bool valid = item < lg.n_items;
+  const int id = valid ? lg.item_iv[item] : 0;
+  tc.t0 = valid ? lg.item_t0[item] : 0;
+  const int64_t T = iv.len[id];
+  tc.ns = valid ? (int)min((int64_t)lg.L, T - tc.t0) : 0;
+  int nsmax = tc.ns;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) nsmax = max(nsmax, __shfl_xor(nsmax, o));
+  tc.nsmax = __builtin_amdgcn_readfirstlane(nsmax);
+  tc.orow = obs + (iv.pos0[id] + tc.t0) * KP;
+  tc.tb2 = (((tile >> 2) * lg.L) * 4 + (tile & 3)) * (int64_t)(al32_pairs(NT) * 64);
+  return tc;
+}
+
+// ------------------------------------------------------------------------------------------
+// xi:  C[i][j] += sum over positions alpha'_t[i] wz_t[j]  and  start += gamma_0.
+// grid = persistent workgroups over the tiles, block = 256 (one tile per wave at a time), no LDS.
+// GEMM role of a lane: operand row m = lane & 15 -> (pp = m >> 2, kq = m & 3), contraction index k = lane >> 4
+// -> item 4 kk + k of the tile.
+// ------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k_estep_xi(IntervalTab iv, LaneGeom lg, int N, const float *__restrict__ al32,
+                                                  const float *__restrict__ gam32, const float *__restrict__ wz32,
+                                                  double *gC, double *gstart) {
+  using G = EstepGeom<NT>;
+  constexpr int KS = G::KS, P = G::P, PQ = G::PQ, NTILE = G::NTILE;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int kq = lane >> 4, i16 = lane & 15;
+  const int g_pp = (lane & 15) >> 2, g_kq = lane & 3, g_k = lane >> 4;
+  lane_d4 acc[NTILE][NTILE];
+#pragma unroll
+  for (int a = 0; a < NTILE; ++a)
+#pragma unroll
+    for (int b = 0; b < NTILE; ++b) acc[a][b] = (lane_d4){0.0, 0.0, 0.0, 0.0};
+  const int64_t n_tiles = (int64_t)lg.n_groups * 4;
+  const float2 *gam2 = (const float2 *)gam32, *al2 = (const float2 *)al32, *wz2 = (const float2 *)wz32;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wv; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const EstepTile tc = estep_tile<NT>(iv, lg, tile, i16, 0, nullptr);
+    if (tc.nsmax <= 0) continue;
+    // start statistics: gamma_0 of every interval (lane = (item, state quarter), as the passes stored it)
+    if (tc.ns > 0 && tc.t0 == 0) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const float2 g = gam2[tc.tb2 + kq * 16 + i16 + p * 64];
+        if (kq + 8 * p < N) estep_atomic_add(&gstart[kq + 8 * p], (double)g.x);
+        if (kq + 8 * p + 4 < N) estep_atomic_add(&gstart[kq + 8 * p + 4], (double)g.y);
+      }
+    }
+    const int64_t gb2 = tc.tb2 + g_kq * 16 + g_k;                  // + (4 q + pp) * 64 + 4 kk, + 256 P per position
+    float2 xa[PQ][4], xw[PQ][4];                                   // operands of the step being requested
+    auto request = [&](int s) {
+#pragma unroll
+      for (int q = 0; q < PQ; ++q)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const bool have = 4 * q + g_pp < P;
+          const int64_t ix = gb2 + (int64_t)s * (256 * P) + (4 * q + g_pp) * 64 + 4 * kk;
+          xa[q][kk] = have ? al2[ix] : make_float2(0.f, 0.f);
+          xw[q][kk] = have ? wz2[ix] : make_float2(0.f, 0.f);
+        }
+    };
+    request(0);
+    for (int s = 0; s < tc.nsmax; ++s) {
+      double a[4][NTILE], w[4][NTILE];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) {
+          a[kk][t] = (double)((t & 1) ? xa[t >> 1][kk].y : xa[t >> 1][kk].x);
+          w[kk][t] = (double)((t & 1) ? xw[t >> 1][kk].y : xw[t >> 1][kk].x);
+        }
+      if (s + 1 < tc.nsmax) request(s + 1);          // (positions beyond an item's end hold zeros: never written)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int ta = 0; ta < NTILE; ++ta)
+#pragma unroll
+          for (int tw = 0; tw < NTILE; ++tw)
+            acc[ta][tw] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk][ta], w[kk][tw], acc[ta][tw], 0, 0, 0);
+    }
+  }
+  // accumulator (lane, register r) of tile pair (ta, tw) is C[state(ta, 4 r + (lane >> 4))][state(tw, lane & 15)]
+#pragma unroll
+  for (int ta = 0; ta < NTILE; ++ta)
+#pragma unroll
+    for (int tw = 0; tw < NTILE; ++tw)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = G::state(ta, 4 * r + (lane >> 4)), j = G::state(tw, lane & 15);
+        const double v = acc[ta][tw][r];
+        if (i < N && j < N && v != 0.0) estep_atomic_add(&gC[i * NT + j], v);
+      }
+}
+
+// ------------------------------------------------------------------------------------------
+// Emission histograms of the tracks with few symbols, on the matrix cores:
+//   stat[(track, symbol)][j] += sum over positions [obs_t[track] == symbol] gamma_t[j]
+// = (one-hot rows) x (gamma rows), contracted over the items of the tile exactly like the xi product: operand A
+// of row tile rt is 1.0 where the item's symbol of the row's track equals the row's symbol.
+// grid (x = persistent workgroups over the tiles, y = group of RTG row tiles), block = 256, no LDS.
+// ------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k_estep_hist_mfma(IntervalTab iv, LaneGeom lg, const EstepGroups *__restrict__ egp,
+                                                         int N, int KP, const uint8_t *__restrict__ obs,
+                                                         const float *__restrict__ gam32, double *gstat) {
+  using G = EstepGeom<NT>;
+  constexpr int P = G::P, PQ = G::PQ, NTILE = G::NTILE, RTG = G::RTG;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i16 = lane & 15;
+  const int g_pp = (lane & 15) >> 2, g_kq = lane & 3, g_k = lane >> 4;
+  const int rt0 = blockIdx.y * RTG;
+  const int nrt = min(RTG, egp->n_rt - rt0);
+  // this lane's row of every row tile: observation column and symbol
+  int rcol[RTG], rsym[RTG];
+#pragma unroll
+  for (int r = 0; r < RTG; ++r) {
+    const int inf = r < nrt ? egp->rt_info[(rt0 + r) * 16 + (lane & 15)] : -1;
+    rcol[r] = inf < 0 ? 0 : (inf & 255);
+    rsym[r] = inf < 0 ? 0x7fffffff : (inf >> 8);
+  }
+  lane_d4 acc[RTG][NTILE];
+#pragma unroll
+  for (int a = 0; a < RTG; ++a)
+#pragma unroll
+    for (int b = 0; b < NTILE; ++b) acc[a][b] = (lane_d4){0.0, 0.0, 0.0, 0.0};
+  const int64_t n_tiles = (int64_t)lg.n_groups * 4;
+  const float2 *gam2 = (const float2 *)gam32;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wv; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const EstepTile tc = estep_tile<NT>(iv, lg, tile, i16, KP, obs);
+    if (tc.nsmax <= 0) continue;
+    // the four items this lane contracts over (item 4 kk + g_k of the tile): observation rows and lengths
+    const uint8_t *op[4];
+    int nsk[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int src = 4 * kk + g_k;                                 // lane (src) holds that item's data
+      nsk[kk] = __shfl(tc.ns, src);
+      const unsigned long long pa = (unsigned long long)tc.orow;
+      const unsigned lo = (unsigned)__shfl((int)(unsigned)pa, src), hi = (unsigned)__shfl((int)(unsigned)(pa >> 32), src);
+      op[kk] = (const uint8_t *)(((unsigned long long)hi << 32) | lo);
+    }
+    const int64_t gb2 = tc.tb2 + g_kq * 16 + g_k;
+    float2 xg[PQ][4];
+    int sy[RTG][4];                                                 // symbols of the step being requested
+    auto request = [&](int s) {
+#pragma unroll
+      for (int q = 0; q < PQ; ++q)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const bool have = 4 * q + g_pp < P && s < nsk[kk];
+          xg[q][kk] = have ? gam2[gb2 + (int64_t)s * (256 * P) + (4 * q + g_pp) * 64 + 4 * kk] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+      for (int r = 0; r < RTG; ++r)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          sy[r][kk] = (r < nrt && s < nsk[kk]) ? (int)op[kk][(int64_t)s * KP + rcol[r]] : -1;
+    };
+    request(0);
+    for (int s = 0; s < tc.nsmax; ++s) {
+      double a[4][RTG], w[4][NTILE];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int r = 0; r < RTG; ++r) a[kk][r] = __hiloint2double(sy[r][kk] == rsym[r] ? 0x3ff00000 : 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) w[kk][t] = (double)((t & 1) ? xg[t >> 1][kk].y : xg[t >> 1][kk].x);
+      }
+      if (s + 1 < tc.nsmax) request(s + 1);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int r = 0; r < RTG; ++r)
+          if (r < nrt) {
+#pragma unroll
+            for (int tw = 0; tw < NTILE; ++tw)
+              acc[r][tw] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk][r], w[kk][tw], acc[r][tw], 0, 0, 0);
+          }
+    }
+  }
+  // accumulator (lane, register q) of (row tile r, state tile tw): row 4 q + (lane >> 4), state(tw, lane & 15)
+#pragma unroll
+  for (int r = 0; r < RTG; ++r) {
+    if (r >= nrt) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = (rt0 + r) * 16 + 4 * q + (lane >> 4);
+      const int grow = egp->rt_info[row] < 0 ? -1 : egp->rt_grow[row];
+#pragma unroll
+      for (int tw = 0; tw < NTILE; ++tw) {
+        const int j = G::state(tw, lane & 15);
+        const double v = acc[r][tw][q];
+        if (grow >= 0 && j < N && v != 0.0) estep_atomic_add(&gstat[(int64_t)grow * NT + j], v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Emission histograms of the tracks with many symbols: privatised in LDS (fp64), one flush per workgroup.
+// grid (x = persistent workgroups over the tiles, y = LDS group), block = 512 (8 waves, one tile each).
+// LDS: hist [rows][NT] doubles | info [slots] ints.  Lane = (item = lane & 15, state quarter kq = lane >> 4).
+// ------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(512) void k_estep_hist_lds(IntervalTab iv, LaneGeom lg, const EstepGroups *__restrict__ egp,
+                                                        int N, int KP, const uint8_t *__restrict__ obs,
+                                                        const float *__restrict__ gam32, double *gstat) {
+  using G = EstepGeom<NT>;
+  constexpr int KS = G::KS, P = G::P;
+  extern __shared__ double estep_lds[];
+  const int grp = blockIdx.y;
+  const int s0 = egp->first[grp], nslot = egp->first[grp + 1] - s0, rows = egp->rows[grp];
+  double *hist = estep_lds;
+  int *tinfo = (int *)(hist + (size_t)rows * NT);
+  for (int i = threadIdx.x; i < rows * NT; i += blockDim.x) hist[i] = 0.0;
+  for (int i = threadIdx.x; i < nslot; i += blockDim.x) tinfo[i] = egp->info[s0 + i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int kq = lane >> 4, i16 = lane & 15;
+  const int64_t n_tiles = (int64_t)lg.n_groups * 4;
+  const float2 *gam2 = (const float2 *)gam32;
+  for (int64_t tile = (int64_t)blockIdx.x * 8 + wv; tile < n_tiles; tile += (int64_t)gridDim.x * 8) {
+    const EstepTile tc = estep_tile<NT>(iv, lg, tile, i16, KP, obs);
+    if (tc.nsmax <= 0) continue;
+    const int64_t hb2 = tc.tb2 + kq * 16 + i16;                                  // + p * 64
+    float2 gn[P];
+    uint32_t on[4];
+    auto request = [&](int s) {
+      const bool ok = s < tc.ns;
+#pragma unroll
+      for (int p = 0; p < P; ++p) gn[p] = ok ? gam2[hb2 + (int64_t)s * (256 * P) + p * 64] : make_float2(0.f, 0.f);
+      const uint32_t *ow = (const uint32_t *)(tc.orow + (int64_t)s * KP);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) on[d] = (ok && 4 * d < KP) ? ow[d] : 0u;
+    };
+    request(0);
+    for (int s = 0; s < tc.nsmax; ++s) {
+      float2 gc[P];
+      uint32_t oc[4];
+#pragma unroll
+      for (int p = 0; p < P; ++p) gc[p] = gn[p];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) oc[d] = on[d];
+      if (s + 1 < tc.nsmax) request(s + 1);
+      const bool live = s < tc.ns;
+      for (int j = 0; j < nslot; ++j) {
+        const int inf = tinfo[j];
+        const int col = inf & 127, cnt = (inf >> 7) & 511, lb = (int)((unsigned)inf >> 16);
+        uint32_t word = oc[0];
+#pragma unroll
+        for (int d = 1; d < 4; ++d) word = (col >> 2) == d ? oc[d] : word;
+        int sym = (int)((word >> ((col & 3) * 8)) & 0xffu);
+        if (col >= 16) sym = live ? (int)tc.orow[(int64_t)s * KP + col] : 0;
+        // (a symbol beyond the track's last one lands in the reference's padding cells, which
+        //  emission.maximize never reads: not booked)
+        if (live && sym < cnt) {
+          double *hr = hist + (size_t)(lb + sym) * NT + kq;
+#pragma unroll
+          for (int k = 0; k < KS; ++k)
+            if (kq + 4 * k < N) atomicAdd(hr + 4 * k, (double)((k & 1) ? gc[k >> 1].y : gc[k >> 1].x));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // flush: LDS row (lbase + s) -> global row (gbase + s)
+  for (int j = 0; j < nslot; ++j) {
+    const int inf = tinfo[j];
+    const int cnt = (inf >> 7) & 511, lb = (int)((unsigned)inf >> 16);
+    const int gb = egp->gbase[s0 + j];
+    for (int i = threadIdx.x; i < cnt * NT; i += blockDim.x) {
+      const double v = hist[(size_t)lb * NT + i];
+      if (v != 0.0) estep_atomic_add(&gstat[(int64_t)gb * NT + i], v);
+    }
+  }
+}
+
+}  // namespace tehmm

@@ -464,11 +464,16 @@ void k_fused_fwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu
 // keeps beta_t at the positions == 31 (mod 64), where k_fb_fix checks its direction.
 // Item-relative step s (L + Wu - 1 down to 0) <-> extended step s + Wu.
 // ------------------------------------------------------------------------------------------
-template <int NT, bool LOGDOM, bool EPS>
+// ESTEP (Baum-Welch E-step, tehmm_estep.hip.h): instead of the posterior rows the pass leaves, as floats in the
+// alpha' layout (al32_index), gamma_t = normalise(alpha'_t * beta_t) (no eps: fit, basehmm.py:516-517) and
+// wz_t = w_{t+1} * scale_t / G_t, the row that makes xi_t(i, j) = alpha'_t[i] A[i][j] wz_t[j] sum to one
+// (_hmm.pyx:62-117 in the scaled linear domain; G_t = sum_j alpha'_t[j] beta_t[j], scale_t the power of two
+// that normalised beta_t): k_estep_reduce turns the three float rows of a position into the statistics.
+template <int NT, bool LOGDOM, bool EPS, bool ESTEP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= TEHMM_FUSED_2W ? 2 : 1, NT <= TEHMM_FUSED_2W ? 2 : 1)))
 void k_fused_bwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu,
                  const double *__restrict__ tab /* A, [NT][NT] row-major */, const float *__restrict__ al32,
-                 double *post, double *pre, double *end, double *chk) {
+                 double *post, double *pre, double *end, double *chk, float *gam32 = nullptr, float *wz32 = nullptr) {
   using G = FusedGeom<NT>;
   constexpr int KS = G::KS, RT = G::RT;
   extern __shared__ double fused_lds[];
@@ -529,7 +534,7 @@ void k_fused_bwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu
   const unsigned ptile = (unsigned)(size_t)(__attribute__((address_space(3))) const double *)fused_lds +
                          (unsigned)(ft.lds_rows * G::ROW_D_LDS * 8 + 4 * 2 * 3072 + (threadIdx.x >> 6) * (16 * NT * 8 + 128));
   const unsigned pinfo = ptile + 16 * NT * 8;
-  if (kq == 0) *(lds_i64 *)(size_t)(pinfo + (lane & 15) * 8) = run ? (long long)prow0 : -1ll;
+  if (!ESTEP && kq == 0) *(lds_i64 *)(size_t)(pinfo + (lane & 15) * 8) = run ? (long long)prow0 : -1ll;
   double q[KS], ms;
   EmisStream<NT, LOGDOM> es(ft, fused_lds, win, kq);
   es.begin(L + 2 * Wu - 1);
@@ -597,11 +602,29 @@ void k_fused_bwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu
         g[k] *= inv;
         if (EPS) g[k] = (g[k] + eps) * inv_epsden;
       }
+      float wzf[ESTEP ? KS : 1];
+      if constexpr (ESTEP) {
+        const double wzs = scale * inv;                    // v is still w_{t+1} here
+#pragma unroll
+        for (int k = 0; k < KS; ++k) wzf[k] = (float)(v[k] * wzs);
+      }
 #pragma unroll
       for (int k = 0; k < KS; ++k) v[k] = q[k] * bt[k];
 #pragma unroll
       for (int k = 0; k < KS; ++k) q[k] = qn[k];
       es.begin(max(s - 2 + Wu, 0));       // next step's gather: its first loads go out ahead of the stores below
+      if constexpr (ESTEP) {
+        if (run) {
+          // gamma and wz rows as floats in the alpha' layout: (KS + 1) / 2 stores of 512 bytes per wave and row
+          const int64_t ai = al32_index<NT>(lg, item, s, kq) / 2;
+          float2 *gr = (float2 *)gam32 + ai, *wr = (float2 *)wz32 + ai;
+#pragma unroll
+          for (int p = 0; p < (KS + 1) / 2; ++p) {
+            gr[(int64_t)p * 64] = make_float2((float)g[2 * p], 2 * p + 1 < KS ? (float)g[2 * p + 1] : 0.f);
+            wr[(int64_t)p * 64] = make_float2(wzf[2 * p], 2 * p + 1 < KS ? wzf[2 * p + 1] : 0.f);
+          }
+        }
+      } else {
 #pragma unroll
       for (int k = 0; k < KS; ++k) *(lds_f64 *)(size_t)(ptile + (unsigned)(((lane & 15) * NT + kq + 4 * k) * 8)) = g[k];
       int lane_v = lane;                                   // (opaque: keeps the per-store index arithmetic inside
@@ -615,6 +638,7 @@ void k_fused_bwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu
           const long long base = *(lds_i64 *)(size_t)(pinfo + (unsigned)r * 8u);
           if (base >= 0 && c < N) post[base + (int64_t)s * N + c] = val;
         }
+      }
       }
       if (run) {
         if ((s & 63) == 31) {

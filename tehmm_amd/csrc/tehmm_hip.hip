@@ -6,6 +6,7 @@
 #include "tehmm_lane.hip.h"
 #include "tehmm_aux.hip.h"
 #include "tehmm_fused.hip.h"
+#include "tehmm_estep.hip.h"
 
 #include <algorithm>
 #include <atomic>
@@ -134,6 +135,10 @@ struct EstepWork {
   DBuf<int64_t> grow0, chunk_t0;
   int64_t rows_cap = 0;
   int n_cap = 0, N = 0;
+  // fused (chunk-parallel) E-step: the track groups of k_estep_reduce
+  EstepGroups h_groups;
+  DBuf<EstepGroups> d_groups;
+  uint64_t groups_model = 0;
 };
 
 // chunk bookkeeping of the speculative (chunk-parallel, exact) Viterbi
@@ -161,6 +166,7 @@ struct LaneWork {
   DBuf<double> B, BH, MS, AL, BE, pre_f, end_f, pre_b, end_b, slog32;
   DBuf<double> chk, chkf;     // fused passes: speculative beta / alpha' rows at the chains' check positions
   DBuf<float> AL32;           // fused passes: alpha' rows as floats (al32_index)
+  DBuf<float> GAM32, WZ32;    // fused E-step: gamma and wz rows, same layout (tehmm_estep.hip.h)
   DBuf<unsigned long long> rix;   // fused passes: observation rows as table-row index records (FusedTab::rixx)
   uint64_t rix_model = 0;
   int rix_L = 0, rix_Wu = 0;
@@ -1000,6 +1006,8 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
     lw.dl_b.release();
     lw.B32.release();
     lw.AL32.release();
+    lw.GAM32.release();
+    lw.WZ32.release();
     lw.L = L; lw.CS = CS; lw.NP = m->NP;
     lw.n_items = (int)h_iv.size();
     lw.n_groups = (lw.n_items + 63) / 64;
@@ -1287,7 +1295,8 @@ static void launch_fb_lane(tehmm_batch *b, const tehmm_model *m, const IntervalT
 // [ev_mid] -> backward exact chain (posterior rows of its exact blocks).  ev_fwd: end of the forward half.
 template <int NT>
 static int launch_fused_fb(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em_in,
-                           const FbChunks &fc, int Wu, hipStream_t st, hipEvent_t ev_fwd, hipEvent_t ev_mid) {
+                           const FbChunks &fc, int Wu, hipStream_t st, hipEvent_t ev_fwd, hipEvent_t ev_mid,
+                           bool estep = false) {
   LaneWork &lw = b->lw;
   const LaneGeom lg = lane_geom(lw);
   const dim3 gridm((unsigned)lw.n_groups);           // 4 tiles of 16 items per 256-thread block = one group
@@ -1370,9 +1379,16 @@ static int launch_fused_fb(tehmm_batch *b, const tehmm_model *m, const IntervalT
                        (double *)nullptr, (int *)nullptr, 1, b->sw.stats.p, lg, (const int *)lw.ok_f.p,              \
                        (const double *)lw.chkf.p, (double *)nullptr, lw.AL32.p, (const double *)lw.end_f.p);         \
     (void)hipEventRecord(ev_fwd, st);                                                                                \
-    hipLaunchKernelGGL((k_fused_bwd<NT, LOG_, true>), gridm, dim3(256), lds_b, st, iv, ft, lg, m->N, fc.CS,           \
-                       Wu, (const double *)m->A.p, (const float *)lw.AL32.p, b->post.p, lw.pre_b.p, lw.end_b.p,      \
-                       lw.chk.p);                                                                                    \
+    if (estep) {                                                                                                    \
+      allow_lds(k_fused_bwd<NT, LOG_, false, true>, lds_f);                                                          \
+      hipLaunchKernelGGL((k_fused_bwd<NT, LOG_, false, true>), gridm, dim3(256), lds_f, st, iv, ft, lg, m->N, fc.CS, \
+                         Wu, (const double *)m->A.p, (const float *)lw.AL32.p, (double *)nullptr, lw.pre_b.p,        \
+                         lw.end_b.p, lw.chk.p, lw.GAM32.p, lw.WZ32.p);                                               \
+    } else {                                                                                                        \
+      hipLaunchKernelGGL((k_fused_bwd<NT, LOG_, true>), gridm, dim3(256), lds_b, st, iv, ft, lg, m->N, fc.CS,         \
+                         Wu, (const double *)m->A.p, (const float *)lw.AL32.p, b->post.p, lw.pre_b.p, lw.end_b.p,    \
+                         lw.chk.p);                                                                                  \
+    }                                                                                                               \
   } while (0)
   if (m->ptab_log) TEHMM_FUSED_LAUNCH(true);
   else TEHMM_FUSED_LAUNCH(false);
@@ -1384,6 +1400,16 @@ static int launch_fused_fb(tehmm_batch *b, const tehmm_model *m, const IntervalT
   hipLaunchKernelGGL(k_fb_runs, gridi, dim3(64), 0, st, iv, fc, (const int *)lw.ok_f.p, (const int *)lw.ok_b.p,
                      extend, 2);
   (void)hipEventRecord(ev_mid, st);
+  if (estep) {
+    const size_t lds_e = lds_c + (size_t)64 * (NT + 1) * sizeof(double);
+    allow_lds(k_fb_fix<NT, 1, false, true, true, true>, lds_e);
+    hipLaunchKernelGGL((k_fb_fix<NT, 1, false, true, true, true>), dim3(b->n), dim3(128), lds_e, st, iv, emc, fc, m->N,
+                       m->A.p, m->lt.p, m->pi.p, (const double *)nullptr, (double *)nullptr, b->fwd_lp.p, b->dead.p,
+                       (double *)nullptr, (int *)nullptr, 1, b->sw.stats.p, lg, (const int *)lw.ok_b.p,
+                       (const double *)lw.chk.p, (double *)nullptr, lw.AL32.p, (const double *)nullptr, lw.GAM32.p,
+                       lw.WZ32.p);
+    return TEHMM_OK;
+  }
   hipLaunchKernelGGL((k_fb_fix<NT, 1, false, true, true>), dim3(b->n), dim3(128), lds_c, st, iv, emc, fc, m->N, m->A.p,
                      m->lt.p, m->pi.p, (const double *)nullptr, (double *)nullptr, b->fwd_lp.p, b->dead.p,
                      (double *)nullptr, (int *)nullptr, 1, b->sw.stats.p, lg, (const int *)lw.ok_b.p,
@@ -2248,6 +2274,210 @@ void launch_estep(const tehmm_model *m, const IntervalTab &iv, const EmisTab &em
 }
 }  // namespace
 
+
+// ---- chunk-parallel E-step on the fused posterior passes (tehmm_estep.hip.h) -----------------------------
+// Track partition of the reduction kernels (tehmm_estep.hip.h): tracks of at most TEHMM_ESTEP_SMALL rows are
+// packed into 16-row tiles for the one-hot product on the matrix cores, the others into LDS histogram groups of
+// at most `cap_rows` rows (first fit, decreasing).
+#define TEHMM_ESTEP_SMALL 40
+static void estep_build_groups(const tehmm_model *m, int cap_rows, EstepGroups &eg) {
+  std::memset(&eg, 0, sizeof(eg));
+  const char *sm = std::getenv("TEHMM_ESTEP_SMALL");
+  const int small = sm ? std::atoi(sm) : TEHMM_ESTEP_SMALL;
+  std::vector<int> big;
+  int row = 0;
+  for (int i = 0; i < TEHMM_ESTEP_MAXRT * 16; ++i) eg.rt_info[i] = -1;
+  for (int k = 0; k < m->K; ++k) {
+    if (m->rowcnt[k] <= small && row + m->rowcnt[k] <= TEHMM_ESTEP_MAXRT * 16) {
+      for (int sy = 0; sy < m->rowcnt[k]; ++sy, ++row) {
+        eg.rt_info[row] = (k & 255) | (sy << 8);
+        eg.rt_grow[row] = m->rowbase[k] + sy;
+      }
+    } else {
+      big.push_back(k);
+    }
+  }
+  eg.n_rt = (row + 15) / 16;
+  std::stable_sort(big.begin(), big.end(), [&](int a, int b2) { return m->rowcnt[a] > m->rowcnt[b2]; });
+  std::vector<std::vector<int>> bins;
+  std::vector<int> load;
+  for (int k : big) {
+    size_t g = 0;
+    while (g < bins.size() && load[g] + m->rowcnt[k] > cap_rows) ++g;
+    if (g == bins.size()) { bins.emplace_back(); load.push_back(0); }
+    bins[g].push_back(k);
+    load[g] += m->rowcnt[k];
+  }
+  int slot = 0;
+  eg.n_lds = (int)bins.size();
+  for (size_t g = 0; g < bins.size(); ++g) {
+    eg.first[g] = slot;
+    int lrow = 0;
+    for (int k : bins[g]) {
+      eg.info[slot] = (k & 127) | ((m->rowcnt[k] & 511) << 7) | (lrow << 16);
+      eg.gbase[slot] = m->rowbase[k];
+      lrow += m->rowcnt[k];
+      ++slot;
+    }
+    eg.rows[g] = lrow;
+  }
+  eg.first[bins.size()] = slot;
+}
+
+static bool estep_fused_wanted(const tehmm_model *m, const tehmm_batch *b, bool ratio, int CS) {
+  const char *s = std::getenv("TEHMM_ESTEP_FUSED");
+  if (s && std::atoi(s) == 0) return false;
+  if (ratio || m->N >= 64 || m->NP > 64 || CS <= 0 || b->total < 2 * (int64_t)CS) return false;
+  if (!m->ptab.p || m->K > 78 || m->K > 127) return false;
+  for (int k = 0; k < m->K; ++k)
+    if (m->rowcnt[k] > 511) return false;
+  return true;
+}
+
+template <int NT>
+static void launch_estep_reduce(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, double *dev_stats,
+                                hipStream_t st) {
+  LaneWork &lw = b->lw;
+  EstepWork &w = b->ew;
+  const LaneGeom lg = lane_geom(lw);
+  const EstepGroups &eg = w.h_groups;
+  const int64_t n_tiles = (int64_t)lw.n_groups * 4;
+  double *gC = dev_stats + stats_off_C(m->NP), *gstart = dev_stats + stats_off_start(),
+         *gstat = dev_stats + stats_off_stat(m->NP);
+  // the three reductions are independent: the LDS-atomic histograms (LDS pipe) run next to the two matrix-core
+  // products on their own streams
+  (void)hipEventRecord(b->evX[0], st);
+  const int gxm = (int)std::max<int64_t>(1, std::min<int64_t>((n_tiles + 3) / 4, 512));
+  if (eg.n_lds > 0) {
+    int max_rows = 0;
+    for (int g = 0; g < eg.n_lds; ++g) max_rows = std::max(max_rows, eg.rows[g]);
+    const size_t lds = (size_t)max_rows * NT * sizeof(double) + (size_t)m->K * sizeof(int) + 16;
+    allow_lds(k_estep_hist_lds<NT>, lds);
+    const int gx = (int)std::max<int64_t>(1, std::min<int64_t>((n_tiles + 7) / 8, 256));
+    (void)hipStreamWaitEvent(b->sV, b->evX[0], 0);
+    hipLaunchKernelGGL((k_estep_hist_lds<NT>), dim3(gx, eg.n_lds), dim3(512), lds, b->sV, iv, lg,
+                       (const EstepGroups *)w.d_groups.p, m->N, b->KP, (const uint8_t *)b->obs.p,
+                       (const float *)lw.GAM32.p, gstat);
+    (void)hipEventRecord(b->ev[11], b->sV);
+  }
+  if (eg.n_rt > 0) {
+    constexpr int RTG = EstepGeom<NT>::RTG;
+    (void)hipStreamWaitEvent(b->sB, b->evX[0], 0);
+    hipLaunchKernelGGL((k_estep_hist_mfma<NT>), dim3(gxm, (eg.n_rt + RTG - 1) / RTG), dim3(256), 0, b->sB, iv, lg,
+                       (const EstepGroups *)w.d_groups.p, m->N, b->KP, (const uint8_t *)b->obs.p,
+                       (const float *)lw.GAM32.p, gstat);
+    (void)hipEventRecord(b->evX[1], b->sB);
+  }
+  hipLaunchKernelGGL((k_estep_xi<NT>), dim3(gxm), dim3(256), 0, st, iv, lg, m->N, (const float *)lw.AL32.p,
+                     (const float *)lw.GAM32.p, (const float *)lw.WZ32.p, gC, gstart);
+  if (eg.n_lds > 0) (void)hipStreamWaitEvent(st, b->ev[11], 0);
+  if (eg.n_rt > 0) (void)hipStreamWaitEvent(st, b->evX[1], 0);
+}
+
+// returns TEHMM_OK and *done = true when the fused path ran; *done = false: the caller falls back
+static int estep_fused(tehmm_model_t *m, tehmm_batch_t *b, double *dev_stats, double *lp_out, int *dead_out, bool *done) {
+  *done = false;
+  const int CS = spec_chunk_size();
+  if (!estep_fused_wanted(m, b, false, CS)) return TEHMM_OK;
+  const int LS = lane_sub_size(CS, b->total);
+  if (LS <= 0) return TEHMM_OK;
+  LaneWork &lw = b->lw;
+  EstepWork &w = b->ew;
+  if (!(lw.AL32.p && lw.GAM32.p && lw.L == LS && lw.CS == CS && lw.NP == m->NP)) {
+    // three float rows + index records per position must fit; otherwise the grouped sequential path
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const double per = (double)b->total * (3.0 * 32.0 * al32_pairs(m->NP) + 40.0) * 1.15;
+    if (per > 0.85 * (double)free_b) return TEHMM_OK;
+  }
+  int rc = spec_prepare(b, m, CS);
+  if (rc) return rc;
+  rc = lane_prepare(b, m, CS, LS, true, false, false, true, false);
+  if (rc) return rc;
+  const size_t na = (size_t)std::max(1, lw.n_groups) * LS * 512 * al32_pairs(m->NP);
+  if (!lw.GAM32.p) {
+    HIPCHK(lw.GAM32.alloc(na));
+    HIPCHK(lw.WZ32.alloc(na));
+    HIPCHK(hipMemset(lw.GAM32.p, 0, na * sizeof(float)));      // (slots beyond an interval's end are read, never written)
+    HIPCHK(hipMemset(lw.WZ32.p, 0, na * sizeof(float)));
+  }
+  if (!b->fwd_lp.p || !b->dead.p) {
+    HIPCHK(b->fwd_lp.alloc((size_t)b->n + 1));
+    HIPCHK(b->dead.alloc((size_t)b->n + 1));
+    if (!b->first_good.p) HIPCHK(b->first_good.alloc((size_t)b->n + 1));
+  }
+  if (w.groups_model != m->uid || !w.d_groups.p) {
+    const int cap_rows = (int)((160 * 1024 - (size_t)m->K * sizeof(int) - 64) / ((size_t)m->NP * sizeof(double)));
+    estep_build_groups(m, cap_rows, w.h_groups);
+    HIPCHK(w.d_groups.upload(&w.h_groups, 1));
+    w.groups_model = m->uid;
+  }
+  IntervalTab iv;
+  EmisTab em;
+  fill_tabs(m, b, iv, em, false);
+  SpecWork &sw = b->sw;
+  const char *wus = std::getenv("TEHMM_LANE_WARMUP");
+  const int WuF = std::min(LS, std::max(1, wus ? std::atoi(wus) : 64));
+  FbChunks fc{};
+  fc.iv = sw.iv.p; fc.t0 = sw.t0.p; fc.first = sw.first.p; fc.n = sw.n_chunks; fc.CS = CS;
+  fc.scale = sw.scale.p; fc.wstart = sw.wstart.p;
+  fc.link_f = lw.link_f.p; fc.glog_f = lw.glog_f.p; fc.link_b = lw.link_b.p; fc.runend_f = lw.runend_f.p;
+  fc.pre_f = lw.cpre_f.p; fc.runstart_b = lw.runstart_b.p;
+  hipStream_t st = b->sP;
+  b->tnames.clear();
+  b->tpairs.clear();
+  b->tms.clear();
+  (void)hipEventRecord(b->ev[10], st);
+  (void)hipMemsetAsync(b->dead.p, 0, (size_t)(b->n + 1) * sizeof(int), st);
+  (void)hipMemsetAsync(sw.stats.p + 2, 0, 4 * sizeof(int), st);
+  int rcf = TEHMM_OK;
+#define CALL(NT_) rcf = launch_fused_fb<NT_>(b, m, iv, em, fc, WuF, st, b->ev[8], b->ev[6], true)
+  TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+  if (rcf) return rcf;
+  (void)hipEventRecord(b->ev[7], st);
+#define CALL(NT_) launch_estep_reduce<NT_>(b, m, iv, dev_stats, st)
+  TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+  (void)hipEventRecord(b->ev[9], st);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  static const struct { const char *name; int a, b2; } stages[] = {
+      {"estep_forward_pass", 10, 8}, {"estep_backward_pass", 8, 6}, {"estep_backward_chain", 6, 7}, {"estep_reduce", 7, 9}};
+  for (const auto &sg : stages) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, b->ev[sg.a], b->ev[sg.b2]);
+    b->tnames.push_back(sg.name);
+    b->tms.push_back((double)ms);
+  }
+  {
+    int cnt[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(cnt, sw.stats.p + 2, sizeof(cnt), hipMemcpyDeviceToHost));
+    static const char *names[4] = {"count:forward_exact_blocks", "count:forward_chunk_jumps",
+                                   "count:backward_exact_blocks", "count:backward_chunk_jumps"};
+    for (int i = 0; i < 4; ++i) {
+      b->tnames.push_back(names[i]);
+      b->tms.push_back((double)cnt[i]);
+    }
+  }
+  std::vector<double> lp((size_t)b->n);
+  std::vector<int> dead((size_t)b->n);
+  HIPCHK(hipMemcpy(lp.data(), b->fwd_lp.p, (size_t)b->n * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(dead.data(), b->dead.p, (size_t)b->n * sizeof(int), hipMemcpyDeviceToHost));
+  double lp_total = 0.0;
+  int dead_any = 0;
+  for (int id = 0; id < b->n; ++id) {
+    if (b->h_len[(size_t)id] <= 0) continue;
+    lp_total += lp[(size_t)id];
+    dead_any |= dead[(size_t)id];
+    b->h_fwd_lp[(size_t)id] = dead[(size_t)id] ? std::nan("") : lp[(size_t)id];
+  }
+  *lp_out = lp_total;
+  *dead_out = dead_any;
+  *done = true;
+  return TEHMM_OK;
+}
+
 // Raw statistics of every interval of the batch ADDED into dev_stats (device buffer of
 // stats_size(NP, R) doubles, layout in tehmm_aux.hip.h); *dead_any: some interval met an impossible row
 // after its first emittable one (the reference's lattices are NaN there).
@@ -2263,6 +2493,12 @@ static int estep_accumulate(tehmm_model_t *m, tehmm_batch_t *b, int use_ratios, 
   if (b->n == 0 || b->total == 0) return TEHMM_OK;
   const bool ratio = use_ratios && b->has_ratios;
   const int N = m->N, NP = m->NP;
+  if (!ratio) {
+    bool done = false;
+    int rcf = estep_fused(m, b, dev_stats, lp_out, dead_out, &done);
+    if (rcf) return rcf;
+    if (done) return TEHMM_OK;
+  }
   // Intervals are processed in groups whose alpha / beta / w rows fit a fixed workspace
   // (3 x 8N + 4 bytes per position, 40 % of the free HBM): the 3 Gb training sets of config 4
   // never materialise whole-genome lattices.

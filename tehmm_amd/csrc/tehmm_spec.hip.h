@@ -713,13 +713,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // (endv, the lane pass's end vectors).  Forward: exact rows are written to al32, a jump adopts endv.
 // Backward: al32 is read only and the chain writes the posterior rows normalise(alpha' * beta) of its exact
 // blocks (+ eps quirk) to post.
-template <int NT, int DIR, bool TRATIO, bool LANE, bool FUSED = false>
+// ESTEP (backward chain of the fused E-step): the exact blocks leave gamma and wz rows as floats in the alpha'
+// layout (gam32 / wz32, see k_fused_bwd) instead of posterior rows; LDS grows by one [64][RS] block (the
+// unnormalised wz rows of the block being walked).
+template <int NT, int DIR, bool TRATIO, bool LANE, bool FUSED = false, bool ESTEP = false>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A, const double *g_lt,
               const double *g_pi, const double *tratios, double *rows, double *fwd_logprob,
               int *dead_flag, double *wrows, int *escale, int allow_jump, int *stats, LaneGeom lg,
               const int *okc, const double *chk = nullptr, double *post = nullptr, float *al32 = nullptr,
-              const double *endv = nullptr) {
+              const double *endv = nullptr, float *gam32 = nullptr, float *wz32 = nullptr) {
   extern __shared__ double sm[];
   constexpr int RS = NT + 1;
   constexpr int CPB = 64;
@@ -729,6 +732,7 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
   double *ltab = ltdv + NT;
   volatile int64_t *seqpos = (volatile int64_t *)(ltab + em.lds_rows * NT);
   volatile int *gen = (volatile int *)(seqpos + 4);
+  double *wzu = (double *)(seqpos + 8);          // ESTEP: [64][RS]
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
   const int id = iv.order[blockIdx.x];
@@ -860,6 +864,7 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
           double bt;
           if (t == T - 1) {
             bt = live ? 1.0 : 0.0;
+            if (ESTEP && lane < NT) wzu[p * RS + lane] = 0.0;                 // no transition leaves the last position
           } else {
             double rr[(NT + 15) / 16];
             rep_rows<NT>(v, rr);
@@ -869,6 +874,7 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
             const double ssum = (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]);
             const int e = ((__builtin_amdgcn_readlane(__double2hiint(ssum), NT - 1) >> 20) & 0x7ff) - 1022;
             bt = live ? ldexp(ssum, -e) : 0.0;
+            if (ESTEP && lane < NT) wzu[p * RS + lane] = live ? ldexp(v, -e) : 0.0;   // w_{t+1} * scale_t
           }
           if (FUSED) {
             if (lane < NT) const_cast<double *>(br)[p * RS + lane] = bt;      // (the bh slot of this step is free)
@@ -890,7 +896,20 @@ void k_fb_fix(IntervalTab iv, EmisTab em, FbChunks fc, int N, const double *g_A,
           if (lane == 0) { seqpos[(it + 1) & 3] = jump ? target : cur + np; *gen = it + 1; }
         }
       }
-      if (FUSED && DIR == 1) {
+      if (FUSED && DIR == 1 && ESTEP) {
+        // gamma and wz rows of this exact block (floats, alpha' layout; the padding states get zeros)
+        for (int p = 0; p < np; ++p) {
+          const int64_t tp = lo + p;
+          const int64_t ai = al32_index<NT>(lg, ifirst + tp / lg.L, tp % lg.L, jl);
+          const double a = live ? (double)al32[ai] : 0.0;
+          const double g = a * (live ? br[p * RS + lane] : 0.0);
+          const double tot = wave_sum_f64(g);
+          if (lane < NT) {
+            gam32[ai] = live ? (float)(g / tot) : 0.f;
+            wz32[ai] = live ? (float)(wzu[p * RS + lane] / tot) : 0.f;
+          }
+        }
+      } else if (FUSED && DIR == 1) {
         // posterior rows of this exact block: lane = state, one wave reduction per row
         const double eps = 1.1920928955078125e-07;
         const double inv_epsden = 1.0 / (1.0 + (double)N * eps);

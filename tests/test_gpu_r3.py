@@ -208,3 +208,97 @@ def test_device_em_two_ranks_match_single_process(n_tables):
         assert_allclose(last, h.last_forward_log_prob, rtol=1e-9)
         assert best_it == h.bestCopy.current_iteration and it == h.current_iteration
     assert_array_equal(got[0][1], got[1][1])                  # the two ranks agree bit for bit
+
+
+# ------------------------------------------------------------------ chunk-parallel (fused) E-step
+def _rel(a, b, floor=1e-9):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    m = np.abs(b) > floor
+    return float(np.max(np.abs(a - b)[m] / np.abs(b)[m])) if m.any() else 0.0
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("N,symbols,gauss,normalize,small", [
+    (35, None, None, 1.0, None),                          # BASELINE configs[3] model: 10 multinomial + 2 gaussian
+    (35, None, None, 1.0, "0"),                           # every track through the LDS histograms
+    (35, None, None, 1.0, "300"),                         # every track through the one-hot matrix product
+    (5, (3, 5, 4), (), 1.0, None),
+    (20, (2, 17, 255, 100, 3), (2,), 1.0, None),
+    (50, (4, 250, 30, 250, 250), (1, 3, 4), 1.0, None),   # three 250-bin tracks at 52 padded states: two LDS groups
+    (63, (2, 2, 3, 250), (3,), 1.0, None),
+    (35, (3, 5, 4, 30), (), 0.5, None),                   # --emFac: log-domain emission rows in the passes
+])
+def test_fused_estep_vs_oracle(monkeypatch, N, symbols, gauss, normalize, small):
+    """tehmm_estep_batch on the chunk-parallel path (k_fused_fwd, k_fused_bwd<ESTEP>, the exact chains, k_estep_xi /
+    k_estep_hist_mfma / k_estep_hist_lds) against the oracle's per-sequence E-step (basehmm.py:504-523,
+    hmm.py:545-574) on ragged intervals -- first / last chunks, tails shorter than a chunk, one-row and sub-chunk
+    intervals walked by the exact chains -- and against the sequential path.  Statistics at 1e-6; the observed
+    error (floats rows, fp64 sums) is asserted at 3e-7 so that a loss of margin shows."""
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    from oracle import oracle
+    for k in ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_ESTEP_FUSED", "TEHMM_ESTEP_SMALL"):
+        monkeypatch.delenv(k, raising=False)
+    if small is not None:
+        monkeypatch.setenv("TEHMM_ESTEP_SMALL", small)
+    if symbols is None:
+        model = synth.make_model(N, synth.CONFIG4_SYMBOLS, synth.CONFIG4_GAUSSIAN, seed=12)
+    else:
+        model = synth.make_model(N, symbols, gauss, seed=12 + N)
+    rs = np.random.RandomState(3 + N)
+    lens = [int(x) for x in rs.randint(20000, 45000, size=5)] + [1, 70, 1500, 1024, 2048 + 64, 4097]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = synth.sample_obs(model, int(offs[-1]), seed=5, missing=0.02)
+    K, _, S = model.log_probs.shape
+    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, normalize, model.symbols_per_track)
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TEHMM_ESTEP_FUSED", mode)
+        hb = HipBatch(obs, offs)
+        start, trans, st = np.zeros(N), np.zeros((N, N)), np.zeros((K, N, S))
+        lp = hm.estep(hb, False, start, trans, st)
+        tm = hb.timing()
+        got[mode] = (lp, start, trans, st, hb.interval_logprobs())
+        hb.close()
+        assert ("estep_reduce" in tm) == (mode == "1")
+        if mode == "1":
+            assert tm["count:backward_chunk_jumps"] > 0 and tm["count:forward_chunk_jumps"] > 0
+    ref = oracle.estep([obs[offs[i]:offs[i + 1]] for i in range(len(lens))], model.log_probs, model.log_startprob,
+                       model.log_transmat, normalize, None)
+    lp, start, trans, st, ilp = got["1"]
+    assert_allclose(lp, ref["logprob"], rtol=1e-9)
+    assert_allclose(ilp.sum(), ref["logprob"], rtol=1e-9)
+    assert_allclose(start, ref["start"], rtol=RTOL, atol=1e-12)
+    assert_allclose(trans, ref["trans"], rtol=RTOL, atol=1e-9)
+    assert_allclose(st, ref["obs"], rtol=RTOL, atol=1e-9)
+    worst = max(_rel(start, ref["start"]), _rel(trans, ref["trans"], 1e-6), _rel(st, ref["obs"], 1e-6))
+    print("fused E-step N=%d: max rel error of the statistics %.3g" % (N, worst))
+    assert worst <= 3e-7
+    assert_allclose(got["1"][4], got["0"][4], rtol=1e-9)          # per-interval log-likelihoods of the two paths
+    assert_allclose(got["0"][2], ref["trans"], rtol=RTOL, atol=1e-9)
+
+
+def test_fused_estep_impossible_rows_poison_like_the_reference(monkeypatch):
+    """An interval with a row no state can emit AFTER its first emittable one: the reference's lattices are NaN from
+    there on, so are its statistics.  The fused path must say so too (the forward chain flags the interval)."""
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    monkeypatch.delenv("TEHMM_ESTEP_FUSED", raising=False)
+    model = synth.make_model(6, (3, 5, 4), (), seed=21)
+    lp3 = model.log_probs.copy()
+    lp3[1, :, 2] = -np.inf                      # symbol 2 of track 1 cannot be emitted by any state
+    lens = [5000, 3000]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = synth.sample_obs(model, int(offs[-1]), seed=6)
+    obs[obs[:, 1] == 2, 1] = 1
+    obs[6500, 1] = 2                            # inside the second interval
+    hm = HipModel(model.log_transmat, model.log_startprob, lp3, 1.0, model.symbols_per_track)
+    hb = HipBatch(obs, offs)
+    K, N, S = lp3.shape
+    start, trans, st = np.zeros(N), np.zeros((N, N)), np.zeros((K, N, S))
+    lp = hm.estep(hb, False, start, trans, st)
+    ilp = hb.interval_logprobs()
+    assert "estep_reduce" in hb.timing()
+    hb.close()
+    assert np.isnan(lp) and np.isnan(trans).all() and np.isnan(st).any()
+    assert np.isfinite(ilp[0]) and np.isnan(ilp[1])

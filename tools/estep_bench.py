@@ -36,6 +36,7 @@ def main():
         dt = time.perf_counter() - t0
         print("E-step %d: %.1f Mb in %d chunks: %.3f s -> %.3e positions/s  (logprob %.6e, sum(trans)=%.3f, "
               "sum(obs)=%.1f)" % (it, mb, len(lens), dt, total / dt, lp, trans.sum(), st.sum()))
+        print("   stages (ms):", {k: round(v, 2) for k, v in hb.timing().items()})
 
 
 if __name__ == "__main__":
