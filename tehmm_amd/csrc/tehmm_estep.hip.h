@@ -60,7 +60,7 @@ struct EstepGeom {
   static constexpr int PQ = (P + 3) / 4;                 // pair quads
   // state tiles (q, h): states 8 (4 q + pp) + 4 h + kq; a tile exists when its first state does
   static constexpr int NTILE = 2 * PQ - ((32 * (PQ - 1) + 4 < NT) ? 0 : 1);
-  static constexpr int RTG = 24 / NTILE;                 // row tiles per workgroup role of the one-hot reduction
+  static constexpr int RTG = 24 / NTILE;                 // row tiles per workgroup role of the one-hot reduction (96 accumulator doubles)
   static __host__ __device__ constexpr int state(int tile, int m) {
     return 8 * (4 * (tile >> 1) + (m >> 2)) + 4 * (tile & 1) + (m & 3);
   }
@@ -181,28 +181,28 @@ __global__ __launch_bounds__(256) void k_estep_xi(IntervalTab iv, LaneGeom lg, i
 // of row tile rt is 1.0 where the item's symbol of the row's track equals the row's symbol.
 // grid (x = persistent workgroups over the tiles, y = group of RTG row tiles), block = 256, no LDS.
 // ------------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(256) void k_estep_hist_mfma(IntervalTab iv, LaneGeom lg, const EstepGroups *__restrict__ egp,
-                                                         int N, int KP, const uint8_t *__restrict__ obs,
-                                                         const float *__restrict__ gam32, double *gstat) {
+// (RT = the row tiles this workgroup role really has: the schedule is branch-free and without padding tiles)
+template <int NT, int RT>
+__device__ __forceinline__ void estep_hist_mfma_run(const IntervalTab &iv, const LaneGeom &lg, const EstepGroups *__restrict__ egp,
+                                                    int N, int KP, const uint8_t *__restrict__ obs,
+                                                    const float *__restrict__ gam32, double *gstat, int rt0) {
   using G = EstepGeom<NT>;
-  constexpr int P = G::P, PQ = G::PQ, NTILE = G::NTILE, RTG = G::RTG;
+  constexpr int P = G::P, PQ = G::PQ, NTILE = G::NTILE;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i16 = lane & 15;
   const int g_pp = (lane & 15) >> 2, g_kq = lane & 3, g_k = lane >> 4;
-  const int rt0 = blockIdx.y * RTG;
-  const int nrt = min(RTG, egp->n_rt - rt0);
-  // this lane's row of every row tile: observation column and symbol
-  int rcol[RTG], rsym[RTG];
+  // this lane's row of every row tile: observation column and symbol (padding rows: a symbol no observation
+  // byte of a small track can take, so their products are zero)
+  int rcol[RT], rsym[RT];
 #pragma unroll
-  for (int r = 0; r < RTG; ++r) {
-    const int inf = r < nrt ? egp->rt_info[(rt0 + r) * 16 + (lane & 15)] : -1;
+  for (int r = 0; r < RT; ++r) {
+    const int inf = egp->rt_info[(rt0 + r) * 16 + (lane & 15)];
     rcol[r] = inf < 0 ? 0 : (inf & 255);
-    rsym[r] = inf < 0 ? 0x7fffffff : (inf >> 8);
+    rsym[r] = inf < 0 ? 0x100 : (inf >> 8);
   }
-  lane_d4 acc[RTG][NTILE];
+  lane_d4 acc[RT][NTILE];
 #pragma unroll
-  for (int a = 0; a < RTG; ++a)
+  for (int a = 0; a < RT; ++a)
 #pragma unroll
     for (int b = 0; b < NTILE; ++b) acc[a][b] = (lane_d4){0.0, 0.0, 0.0, 0.0};
   const int64_t n_tiles = (int64_t)lg.n_groups * 4;
@@ -211,19 +211,20 @@ __global__ __launch_bounds__(256) void k_estep_hist_mfma(IntervalTab iv, LaneGeo
     const EstepTile tc = estep_tile<NT>(iv, lg, tile, i16, KP, obs);
     if (tc.nsmax <= 0) continue;
     // the four items this lane contracts over (item 4 kk + g_k of the tile): observation rows and lengths
-    const uint8_t *op[4];
+    int64_t oo[4];
     int nsk[4];
+    const int64_t myoff = tc.orow - obs;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const int src = 4 * kk + g_k;                                 // lane (src) holds that item's data
+      const int src = 4 * kk + g_k;                                 // lane `src` holds that item's data
       nsk[kk] = __shfl(tc.ns, src);
-      const unsigned long long pa = (unsigned long long)tc.orow;
-      const unsigned lo = (unsigned)__shfl((int)(unsigned)pa, src), hi = (unsigned)__shfl((int)(unsigned)(pa >> 32), src);
-      op[kk] = (const uint8_t *)(((unsigned long long)hi << 32) | lo);
+      const unsigned lo = (unsigned)__shfl((int)(unsigned)(unsigned long long)myoff, src);
+      const unsigned hi = (unsigned)__shfl((int)(unsigned)((unsigned long long)myoff >> 32), src);
+      oo[kk] = (int64_t)(((unsigned long long)hi << 32) | lo);
     }
     const int64_t gb2 = tc.tb2 + g_kq * 16 + g_k;
     float2 xg[PQ][4];
-    int sy[RTG][4];                                                 // symbols of the step being requested
+    int sy[RT][4];                                                  // symbols of the step being requested
     auto request = [&](int s) {
 #pragma unroll
       for (int q = 0; q < PQ; ++q)
@@ -233,18 +234,18 @@ __global__ __launch_bounds__(256) void k_estep_hist_mfma(IntervalTab iv, LaneGeo
           xg[q][kk] = have ? gam2[gb2 + (int64_t)s * (256 * P) + (4 * q + g_pp) * 64 + 4 * kk] : make_float2(0.f, 0.f);
         }
 #pragma unroll
-      for (int r = 0; r < RTG; ++r)
+      for (int r = 0; r < RT; ++r)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
-          sy[r][kk] = (r < nrt && s < nsk[kk]) ? (int)op[kk][(int64_t)s * KP + rcol[r]] : -1;
+          sy[r][kk] = s < nsk[kk] ? (int)obs[oo[kk] + (int64_t)s * KP + rcol[r]] : 0xff;
     };
     request(0);
     for (int s = 0; s < tc.nsmax; ++s) {
-      double a[4][RTG], w[4][NTILE];
+      double a[4][RT], w[4][NTILE];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-        for (int r = 0; r < RTG; ++r) a[kk][r] = __hiloint2double(sy[r][kk] == rsym[r] ? 0x3ff00000 : 0, 0);
+        for (int r = 0; r < RT; ++r) a[kk][r] = __hiloint2double(sy[r][kk] == rsym[r] ? 0x3ff00000 : 0, 0);
 #pragma unroll
         for (int t = 0; t < NTILE; ++t) w[kk][t] = (double)((t & 1) ? xg[t >> 1][kk].y : xg[t >> 1][kk].x);
       }
@@ -252,18 +253,15 @@ __global__ __launch_bounds__(256) void k_estep_hist_mfma(IntervalTab iv, LaneGeo
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-        for (int r = 0; r < RTG; ++r)
-          if (r < nrt) {
+        for (int r = 0; r < RT; ++r)
 #pragma unroll
-            for (int tw = 0; tw < NTILE; ++tw)
-              acc[r][tw] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk][r], w[kk][tw], acc[r][tw], 0, 0, 0);
-          }
+          for (int tw = 0; tw < NTILE; ++tw)
+            acc[r][tw] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk][r], w[kk][tw], acc[r][tw], 0, 0, 0);
     }
   }
   // accumulator (lane, register q) of (row tile r, state tile tw): row 4 q + (lane >> 4), state(tw, lane & 15)
 #pragma unroll
-  for (int r = 0; r < RTG; ++r) {
-    if (r >= nrt) continue;
+  for (int r = 0; r < RT; ++r) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int row = (rt0 + r) * 16 + 4 * q + (lane >> 4);
@@ -276,6 +274,19 @@ __global__ __launch_bounds__(256) void k_estep_hist_mfma(IntervalTab iv, LaneGeo
       }
     }
   }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_estep_hist_mfma(IntervalTab iv, LaneGeom lg, const EstepGroups *__restrict__ egp,
+                                                         int N, int KP, const uint8_t *__restrict__ obs,
+                                                         const float *__restrict__ gam32, double *gstat) {
+  constexpr int RTG = EstepGeom<NT>::RTG;
+  const int rt0 = blockIdx.y * RTG;
+  const int nrt = min(RTG, egp->n_rt - rt0);
+#define TEHMM_RUN(RT_)                                                                                       \
+  if (RT_ <= RTG && nrt == RT_) { estep_hist_mfma_run<NT, (RT_ <= RTG ? RT_ : 1)>(iv, lg, egp, N, KP, obs, gam32, gstat, rt0); return; }
+  TEHMM_RUN(8) TEHMM_RUN(7) TEHMM_RUN(6) TEHMM_RUN(5) TEHMM_RUN(4) TEHMM_RUN(3) TEHMM_RUN(2) TEHMM_RUN(1)
+#undef TEHMM_RUN
 }
 
 // ------------------------------------------------------------------------------------------
