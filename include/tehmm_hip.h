@@ -141,6 +141,11 @@ int tehmm_eval_batch(tehmm_model_t *model, tehmm_batch_t *batch, int flags,
  * state sequences), posteriors [total][N]; row range [row0,row1) of the concatenation. */
 int tehmm_batch_get_paths(tehmm_batch_t *batch, int64_t row0, int64_t row1, int64_t *paths);
 int tehmm_batch_get_posteriors(tehmm_batch_t *batch, int64_t row0, int64_t row1, double *post);
+/* Pinned host memory for the destinations above (one DMA at link speed instead of the runtime's bounce buffers;
+ * any other destination is staged in 32 MB pieces through two pinned buffers).  Freed blocks are cached in the
+ * library -- pinning is the slow part -- up to 24 GB. */
+int tehmm_host_alloc(size_t bytes, void **out);
+int tehmm_host_free(void *ptr);
 /* Device pointers of the same buffers (valid until the batch is destroyed or re-evaluated). */
 int tehmm_batch_device_ptrs(tehmm_batch_t *batch, void **paths_i64, void **posteriors_f64);
 

@@ -66,6 +66,8 @@ SIGNATURES = {
     "tehmm_eval_batch": (c_int, [vp, vp, c_int, f64p, f64p]),
     "tehmm_batch_get_paths": (c_int, [vp, c_i64, c_i64, i64p]),
     "tehmm_batch_get_posteriors": (c_int, [vp, c_i64, c_i64, f64p]),
+    "tehmm_host_alloc": (c_int, [ctypes.c_size_t, ctypes.POINTER(vp)]),
+    "tehmm_host_free": (c_int, [vp]),
     "tehmm_batch_device_ptrs": (c_int, [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]),
     "tehmm_estep_batch": (c_int, [vp, vp, c_int, f64p, f64p, f64p, f64p]),
     "tehmm_batch_last_timing": (c_int, [vp, c_int, ctypes.POINTER(ctypes.c_char_p), f64p]),
@@ -111,6 +113,43 @@ def device_count():
     n = c_int(0)
     rc = load().tehmm_device_count(ctypes.byref(n))
     return n.value if rc == 0 else 0
+
+
+class _PinnedBlock(object):
+    """Owner of one tehmm_host_alloc block; the numpy arrays made over it keep it alive."""
+
+    def __init__(self, nbytes):
+        p = vp()
+        check(load().tehmm_host_alloc(max(int(nbytes), 1), ctypes.byref(p)), "tehmm_host_alloc")
+        self.ptr = p
+
+    def __del__(self):
+        if getattr(self, "ptr", None) and _lib is not None:
+            _lib.tehmm_host_free(self.ptr)
+            self.ptr = None
+
+
+def pinned_empty(shape, dtype):
+    """numpy array over pinned host memory (tehmm_host_alloc): D2H copies into it are one DMA."""
+    shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) if shape else 1
+    blk = _PinnedBlock(n * dt.itemsize)
+    buf = (ctypes.c_char * max(n * dt.itemsize, 1)).from_address(blk.ptr.value)
+    arr = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+    return _PinnedArray(arr, blk)
+
+
+class _PinnedArray(np.ndarray):
+    """ndarray view that owns its pinned block."""
+
+    def __new__(cls, arr, blk):
+        obj = arr.view(cls)
+        obj._blk = blk
+        return obj
+
+    def __array_finalize__(self, obj):
+        self._blk = getattr(obj, "_blk", None)
 
 
 def as_f64(a):

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_estep_xi(IntervalTab iv, LaneGeom lg, i
                                                   const float *__restrict__ gam32, const float *__restrict__ wz32,
                                                   double *gC, double *gstart) {
   using G = EstepGeom<NT>;
-  constexpr int KS = G::KS, P = G::P, PQ = G::PQ, NTILE = G::NTILE;
+  constexpr int P = G::P, PQ = G::PQ, NTILE = G::NTILE;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int kq = lane >> 4, i16 = lane & 15;
   const int g_pp = (lane & 15) >> 2, g_kq = lane & 3, g_k = lane >> 4;

@@ -14,8 +14,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/tehmm_hip.h"
@@ -118,6 +120,7 @@ struct tehmm_model {
   DBuf<int> d_rowinfo;         // rowbase[K] | rowcnt[K] | ldsbase[K] on the device
   int KSP = 0;
   uint64_t uid = 0;            // unique per model handle (workspaces derived from the table layout are keyed on it)
+  uint64_t version = 0;        // bumped by every M-step (what depends on the parameter VALUES is keyed on it too)
   bool ptab_log = false;       // log-domain rows (normalizeFac != 1): the product form does not apply
   int rowbase[TEHMM_MAX_TRACKS];
   int rowcnt[TEHMM_MAX_TRACKS];
@@ -170,6 +173,11 @@ struct LaneWork {
   DBuf<unsigned long long> rix;   // fused passes: observation rows as table-row index records (FusedTab::rixx)
   uint64_t rix_model = 0;
   int rix_L = 0, rix_Wu = 0;
+  // forward / backward warm-up measured by k_fb_probe for (model, parameter version, item length)
+  uint64_t wu_model = 0, wu_version = 0;
+  int wu_L = 0, wu_val = 0;
+  DBuf<int> probe_iv, probe_steps;
+  DBuf<int64_t> probe_t0;
   // Viterbi lane passes
   DBuf<double> vpre, vend, vgain, vtierows, vpiecemin, qtabs;
   DBuf<float> B32;
@@ -212,6 +220,7 @@ struct tehmm_batch {
   DBuf<double> vit_lp, fwd_lp;
   DBuf<int64_t> first_good;
   hipStream_t sV = nullptr, sP = nullptr, sB = nullptr;
+  void *stage[2] = {nullptr, nullptr};     // pinned staging buffers of the D2H path (allocated on first use)
   hipEvent_t evX[2] = {nullptr, nullptr};
   hipEvent_t ev[16];
   int n_ev = 0;
@@ -663,6 +672,8 @@ int tehmm_batch_destroy(tehmm_batch_t *b) {
   if (b->sB) (void)hipStreamDestroy(b->sB);
   for (int i = 0; i < 2; ++i)
     if (b->evX[i]) (void)hipEventDestroy(b->evX[i]);
+  for (int i = 0; i < 2; ++i)
+    if (b->stage[i]) (void)hipHostFree(b->stage[i]);
   delete b;
   return TEHMM_OK;
 }
@@ -674,6 +685,7 @@ int tehmm_batch_reset_cache(tehmm_batch_t *b) {
   b->lw.rix_model = 0;
   b->lw.rix_L = 0;
   b->lw.rix_Wu = 0;
+  b->lw.wu_val = 0;
   return TEHMM_OK;
 }
 
@@ -1470,6 +1482,73 @@ static void launch_fb_fix(tehmm_batch *b, const tehmm_model *m, const IntervalTa
   }
 #endif
 
+
+// Forward / backward warm-up of the lane passes: TEHMM_LANE_WARMUP if set, else measured on this batch's own
+// observations by k_fb_probe (96 windows per direction; tehmm_spec.hip.h) -- the longest forgetting time seen,
+// plus a fifth, at least 32 and at most the item length.  TEHMM_LANE_PROBE=0: the round-2 constant 64.
+template <int NT>
+static void launch_fb_probe(const tehmm_model *m, const IntervalTab &iv, const EmisTab &emg, int n, int WMAX, const int *p_iv,
+                            const int64_t *p_t0, int *steps, hipStream_t st) {
+  const size_t lds = ((size_t)64 * (NT + 1) + 64) * sizeof(double);
+  hipLaunchKernelGGL((k_fb_probe<NT, 0>), dim3(n), dim3(64), lds, st, iv, emg, m->N, (const double *)m->A.p, p_iv, p_t0, WMAX, steps);
+  hipLaunchKernelGGL((k_fb_probe<NT, 1>), dim3(n), dim3(64), lds, st, iv, emg, m->N, (const double *)m->A.p, p_iv + n, p_t0 + n,
+                     WMAX, steps + n);
+}
+
+static int fb_warmup(tehmm_batch *b, const tehmm_model *m, int LS, const IntervalTab &iv, const EmisTab &emg, int *out) {
+  if (const char *wus = std::getenv("TEHMM_LANE_WARMUP")) {
+    *out = std::min(LS, std::max(1, std::atoi(wus)));
+    return TEHMM_OK;
+  }
+  *out = std::min(LS, 64);
+  const char *pr = std::getenv("TEHMM_LANE_PROBE");
+  if ((pr && std::atoi(pr) == 0) || m->NP > 64) return TEHMM_OK;
+  LaneWork &lw = b->lw;
+  if (lw.wu_model == m->uid && lw.wu_version == m->version && lw.wu_L == LS && lw.wu_val > 0) {
+    *out = lw.wu_val;
+    return TEHMM_OK;
+  }
+  const int WMAX = std::max(64, std::min(512, LS) & ~63);
+  constexpr int NPR = 96;
+  std::vector<int> cand;
+  for (int i = 0; i < b->n; ++i)
+    if (b->h_len[(size_t)i] >= 2 * (int64_t)WMAX + 128) cand.push_back(i);
+  if (cand.empty()) return TEHMM_OK;
+  std::vector<int> p_iv(2 * NPR);
+  std::vector<int64_t> p_t0(2 * NPR);
+  uint64_t rng = 0x9e3779b97f4a7c15ull ^ (uint64_t)b->total;
+  auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+  for (int k = 0; k < 2 * NPR; ++k) {
+    const int id = cand[(size_t)(next() % cand.size())];
+    const int64_t T = b->h_len[(size_t)id];
+    const int64_t span = (T - 2 * WMAX - 64) / 64;                    // 64-aligned window starts
+    const int64_t a = 64 + 64 * (int64_t)(next() % (uint64_t)std::max<int64_t>(1, span));
+    p_iv[(size_t)k] = id;
+    p_t0[(size_t)k] = k < NPR ? a : a + WMAX;                         // backward windows run down from their end
+  }
+  HIPCHK(lw.probe_iv.upload(p_iv.data(), p_iv.size()));
+  HIPCHK(lw.probe_t0.upload(p_t0.data(), p_t0.size()));
+  HIPCHK(lw.probe_steps.ensure(2 * NPR));
+#define CALL(NT_) launch_fb_probe<NT_>(m, iv, emg, NPR, WMAX, lw.probe_iv.p, lw.probe_t0.p, lw.probe_steps.p, b->sP)
+  TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+  HIPCHK(hipGetLastError());
+  std::vector<int> steps(2 * NPR, 0);
+  HIPCHK(hipMemcpyAsync(steps.data(), lw.probe_steps.p, steps.size() * sizeof(int), hipMemcpyDeviceToHost, b->sP));
+  HIPCHK(hipStreamSynchronize(b->sP));
+  int worst = 0;
+  for (int v : steps) worst = std::max(worst, v);
+  int wu = worst + worst / 5 + 8;
+  wu = (wu + 7) & ~7;
+  wu = std::min(LS, std::max(32, wu));
+  lw.wu_model = m->uid;
+  lw.wu_version = m->version;
+  lw.wu_L = LS;
+  lw.wu_val = wu;
+  *out = wu;
+  return TEHMM_OK;
+}
+
 int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *viterbi_logprob,
                      double *forward_logprob) {
   if (!m || !b) return fail(TEHMM_ERR_ARG, "tehmm_eval_batch: NULL handle");
@@ -1548,8 +1627,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   // the fp64 lane = state pass
   const char *lp0 = std::getenv("TEHMM_LANE_P0");
   const bool glane = vspec && LS > 0 && lane_vit_ok && (vlane || !(lp0 && std::atoi(lp0) == 0));
-  const char *wus = std::getenv("TEHMM_LANE_WARMUP");
-  const int WuF = std::min(LS, std::max(1, wus ? std::atoi(wus) : 64));       // forward / backward warm-up
+  int WuF = std::min(std::max(LS, 1), 64);                                   // forward / backward warm-up (set below)
   const char *wvs = std::getenv("TEHMM_LANE_WARMUP_VIT");
   const int WuV = std::min(LS, std::max(32, ((wvs ? std::atoi(wvs) : 32) + 31) & ~31));   // Viterbi warm-up (multiple of 32)
   VitChunks vc;
@@ -1560,6 +1638,10 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   const bool emis_gain = glane && !(flane && !fused_fb);
   if (vlane || flane || glane) {
     rc = lane_prepare(b, m, CS, LS, flane, vlane, glane, fused_fb, !emis_gain);
+    if (rc) return rc;
+  }
+  if (flane) {
+    rc = fb_warmup(b, m, LS, iv, emg, &WuF);
     if (rc) return rc;
   }
   // Scheduling.  The speculative Viterbi passes, the emission rows, the forward / backward lane passes
@@ -2037,24 +2119,136 @@ int tehmm_batch_get_interval_logprobs(tehmm_batch_t *b, double *out) {
   return TEHMM_OK;
 }
 
+// ---- results over PCIe -------------------------------------------------------------------------------
+// A pageable destination makes hipMemcpy stage through the runtime's own bounce buffers (measured round 2: 5.7 GB
+// of posteriors at 15 GB/s).  Two ways past that:
+//   * tehmm_host_alloc hands out PINNED host memory (cached in a small pool, because pinning is the slow part):
+//     a D2H into it is one DMA at link speed;
+//   * any other destination is served in 32 MB pieces through two pinned staging buffers -- the DMA of piece i + 1
+//     runs while worker threads copy piece i to its destination.
+namespace {
+struct PinnedPool {
+  std::mutex mu;
+  std::vector<std::pair<void *, size_t>> free_blocks;      // cached (ptr, bytes)
+  std::vector<std::pair<void *, size_t>> live;             // handed out
+  size_t cached_bytes = 0;
+} g_pinned;
+constexpr size_t kPinnedCacheMax = (size_t)24 << 30;
+constexpr size_t kStageBytes = (size_t)32 << 20;
+
+bool is_pinned_host(const void *p) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
+
+void threaded_copy(void *dst, const void *src, size_t bytes) {
+  const int nt = bytes >= ((size_t)8 << 20) ? 4 : 1;
+  if (nt == 1) { std::memcpy(dst, src, bytes); return; }
+  std::vector<std::thread> th;
+  const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
+  for (int i = 0; i < nt; ++i) {
+    const size_t a = std::min(bytes, per * i), e = std::min(bytes, per * (i + 1));
+    if (e > a) th.emplace_back([=]() { std::memcpy((char *)dst + a, (const char *)src + a, e - a); });
+  }
+  for (auto &t : th) t.join();
+}
+
+// device -> host of `bytes` bytes on stream `st` (which is synchronised before returning)
+int d2h(void *dst, const void *src, size_t bytes, tehmm_batch *b) {
+  if (bytes == 0) return TEHMM_OK;
+  if (is_pinned_host(dst) || bytes < ((size_t)4 << 20)) {
+    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return TEHMM_OK;
+  }
+  for (int i = 0; i < 2; ++i)
+    if (!b->stage[i]) HIPCHK(hipHostMalloc(&b->stage[i], kStageBytes, hipHostMallocDefault));
+  hipStream_t st = b->sP;
+  const size_t np = (bytes + kStageBytes - 1) / kStageBytes;
+  size_t prev_bytes = 0;
+  for (size_t i = 0; i <= np; ++i) {
+    if (i < np) {
+      const size_t off = i * kStageBytes, nb = std::min(kStageBytes, bytes - off);
+      HIPCHK(hipMemcpyAsync(b->stage[i & 1], (const char *)src + off, nb, hipMemcpyDeviceToHost, st));
+      (void)hipEventRecord(b->evX[i & 1], st);
+      if (i > 0) {                                     // piece i - 1 landed before piece i was queued: copy it out
+        HIPCHK(hipEventSynchronize(b->evX[(i - 1) & 1]));
+        threaded_copy((char *)dst + (i - 1) * kStageBytes, b->stage[(i - 1) & 1], prev_bytes);
+      }
+      prev_bytes = nb;
+    } else {
+      HIPCHK(hipEventSynchronize(b->evX[(i - 1) & 1]));
+      threaded_copy((char *)dst + (i - 1) * kStageBytes, b->stage[(i - 1) & 1], prev_bytes);
+    }
+  }
+  return TEHMM_OK;
+}
+}  // namespace
+
+int tehmm_host_alloc(size_t bytes, void **out) {
+  if (!out || bytes == 0) return fail(TEHMM_ERR_ARG, "tehmm_host_alloc: bad argument");
+  *out = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_pinned.mu);
+    size_t best = SIZE_MAX;
+    for (size_t i = 0; i < g_pinned.free_blocks.size(); ++i)
+      if (g_pinned.free_blocks[i].second >= bytes && g_pinned.free_blocks[i].second <= 2 * bytes + (1 << 20) &&
+          (best == SIZE_MAX || g_pinned.free_blocks[i].second < g_pinned.free_blocks[best].second))
+        best = i;
+    if (best != SIZE_MAX) {
+      auto blk = g_pinned.free_blocks[best];
+      g_pinned.free_blocks.erase(g_pinned.free_blocks.begin() + (long)best);
+      g_pinned.cached_bytes -= blk.second;
+      g_pinned.live.push_back(blk);
+      *out = blk.first;
+      return TEHMM_OK;
+    }
+  }
+  void *p = nullptr;
+  HIPCHK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+  std::lock_guard<std::mutex> lk(g_pinned.mu);
+  g_pinned.live.emplace_back(p, bytes);
+  *out = p;
+  return TEHMM_OK;
+}
+
+int tehmm_host_free(void *p) {
+  if (!p) return TEHMM_OK;
+  std::pair<void *, size_t> blk{nullptr, 0};
+  {
+    std::lock_guard<std::mutex> lk(g_pinned.mu);
+    for (size_t i = 0; i < g_pinned.live.size(); ++i)
+      if (g_pinned.live[i].first == p) {
+        blk = g_pinned.live[i];
+        g_pinned.live.erase(g_pinned.live.begin() + (long)i);
+        break;
+      }
+    if (!blk.first) return fail(TEHMM_ERR_ARG, "tehmm_host_free: not a tehmm_host_alloc block");
+    if (g_pinned.cached_bytes + blk.second <= kPinnedCacheMax) {
+      g_pinned.free_blocks.push_back(blk);
+      g_pinned.cached_bytes += blk.second;
+      return TEHMM_OK;
+    }
+  }
+  HIPCHK(hipHostFree(blk.first));
+  return TEHMM_OK;
+}
+
 int tehmm_batch_get_paths(tehmm_batch_t *b, int64_t row0, int64_t row1, int64_t *paths) {
   if (!b || !paths || row0 < 0 || row1 < row0 || row1 > b->total)
     return fail(TEHMM_ERR_ARG, "tehmm_batch_get_paths: bad argument");
   if (!b->paths.p) return fail(TEHMM_ERR_ARG, "tehmm_batch_get_paths: no Viterbi result in this batch");
-  if (row1 > row0)
-    HIPCHK(hipMemcpy(paths, b->paths.p + row0, (size_t)(row1 - row0) * sizeof(int64_t),
-                     hipMemcpyDeviceToHost));
-  return TEHMM_OK;
+  return d2h(paths, b->paths.p + row0, (size_t)(row1 - row0) * sizeof(int64_t), b);
 }
 
 int tehmm_batch_get_posteriors(tehmm_batch_t *b, int64_t row0, int64_t row1, double *post) {
   if (!b || !post || row0 < 0 || row1 < row0 || row1 > b->total)
     return fail(TEHMM_ERR_ARG, "tehmm_batch_get_posteriors: bad argument");
   if (!b->post.p) return fail(TEHMM_ERR_ARG, "tehmm_batch_get_posteriors: no posterior result in this batch");
-  if (row1 > row0)
-    HIPCHK(hipMemcpy(post, b->post.p + (size_t)row0 * b->N, (size_t)(row1 - row0) * b->N * sizeof(double),
-                     hipMemcpyDeviceToHost));
-  return TEHMM_OK;
+  return d2h(post, b->post.p + (size_t)row0 * b->N, (size_t)(row1 - row0) * b->N * sizeof(double), b);
 }
 
 int tehmm_batch_device_ptrs(tehmm_batch_t *b, void **paths_i64, void **posteriors_f64) {
@@ -2416,8 +2610,9 @@ static int estep_fused(tehmm_model_t *m, tehmm_batch_t *b, double *dev_stats, do
   EmisTab em;
   fill_tabs(m, b, iv, em, false);
   SpecWork &sw = b->sw;
-  const char *wus = std::getenv("TEHMM_LANE_WARMUP");
-  const int WuF = std::min(LS, std::max(1, wus ? std::atoi(wus) : 64));
+  int WuF = 64;
+  rc = fb_warmup(b, m, LS, iv, without_lds_tables(em), &WuF);
+  if (rc) return rc;
   FbChunks fc{};
   fc.iv = sw.iv.p; fc.t0 = sw.t0.p; fc.first = sw.first.p; fc.n = sw.n_chunks; fc.CS = CS;
   fc.scale = sw.scale.p; fc.wstart = sw.wstart.p;

@@ -700,6 +700,75 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ------------------------------------------------------------------------------------------
+// Warm-up probe (round 3).  How many steps the normalised forward (DIR = 0) / backward (DIR = 1) vector needs to
+// forget its start is a property of the model AND the data: 20-50 steps on the dense bench model, several
+// hundred with sparse (-1e100) or sticky (0.995) transitions -- where a fixed 64-step warm-up left thousands of
+// item links unverified and the exact chain walking them (backward_chain 20.8 of 55 ms per 30 Mb, round 2).
+// One wave per probe window: two chains over the SAME observations, one from the uniform vector the lane passes
+// start from, one from a steeply skewed vector (ratio e^-j), until their Hilbert distance is below
+// TEHMM_FB_TOL / 10; steps[w] = the number of steps that took (WMAX if it never got there).
+// blockDim = 64.  LDS (doubles): ring [64][RS] | ms [64]
+// ------------------------------------------------------------------------------------------
+template <int NT, int DIR>
+__global__ __launch_bounds__(64) void k_fb_probe(IntervalTab iv, EmisTab em, int N, const double *g_A, const int *p_iv,
+                                                 const int64_t *p_t0, int WMAX, int *steps) {
+  extern __shared__ double sm[];
+  constexpr int RS = NT + 1;
+  const int lane = threadIdx.x & 63;
+  double *ring = sm;
+  double *ms = sm + 64 * RS;
+  const int jl = min(lane, NT - 1);
+  const bool live = lane < N;
+  double ac[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+    ac[i] = live ? (DIR == 0 ? g_A[i * NT + jl] : g_A[jl * NT + i]) : (lane == NT - 1 ? 1.0 : 0.0);
+  const int id = p_iv[blockIdx.x];
+  const int64_t p0 = iv.pos0[id];
+  const int64_t t0 = p_t0[blockIdx.x];          // DIR 0: first position of the window; DIR 1: one past its last
+  double u = live ? 1.0 / (double)N : 0.0;
+  double v = live ? exp(-(double)lane) : 0.0;
+  bool seen = true;
+  int found = WMAX;
+  for (int blk = 0; blk < WMAX / 64 && found == WMAX; ++blk) {
+    const int64_t lo = DIR == 0 ? t0 + 64 * blk : t0 - 64 * (blk + 1);
+    if (DIR == 0)
+      emis_block<NT, true, true, false>(em, nullptr, p0 + lo, 64, lane, N, seen, nullptr, nullptr, nullptr, ring, RS, ms);
+    else
+      emis_block<NT, true, false, false>(em, nullptr, p0 + lo, 64, lane, N, seen, nullptr, nullptr, nullptr, ring, RS, ms);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    for (int q = 0; q < 64; ++q) {
+      const int p = DIR == 0 ? q : 63 - q;
+      const double bh = ring[p * RS + jl];
+      double x2[2] = {u, v};
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        // forward: a_t = (A^T a_{t-1}) * bh;  backward: w_t = bh * (A w_{t+1})  -- same contraction either way
+        double rr[(NT + 15) / 16];
+        rep_rows<NT>(x2[c], rr);
+        double sacc[4] = {0.0, 0.0, 0.0, 0.0};
+        asm volatile("s_nop 1" ::: "memory");
+        BcastFma<0, NT>::run(rr, ac, sacc);
+        const double ssum = (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]);
+        const int e = ((__builtin_amdgcn_readlane(__double2hiint(ssum), NT - 1) >> 20) & 0x7ff) - 1022;
+        x2[c] = live ? ldexp(ssum * bh, -e) : 0.0;
+      }
+      u = x2[0];
+      v = x2[1];
+      double rho;
+      const double d = proj_dist(u, v, live, rho);
+      if (d <= 0.1 * TEHMM_FB_TOL || !(d == d)) {        // converged (or an impossible row: nothing to learn here)
+        found = 64 * blk + q + 1;
+        break;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0) steps[blockIdx.x] = found;
+}
+
+// ------------------------------------------------------------------------------------------
 // Sequential chain with verified jumps.  blockDim = 128: wave 0 chain, wave 1 emission rows of the
 // next block (same publish / wait protocol as k_vit_fix).  DIR = 0 forward: seqpos = first position
 // of a block (ascending); DIR = 1 backward: seqpos = one past the LAST position of a block

@@ -199,17 +199,22 @@ class HipBatch(object):
         """Forget what earlier evaluations derived from the observations (tehmm_batch_reset_cache)."""
         _lib.check(_lib.load().tehmm_batch_reset_cache(self._h), "tehmm_batch_reset_cache")
 
-    def paths(self, row0=0, row1=None):
+    def paths(self, row0=0, row1=None, pinned=True):
+        """pinned: the result lives in pinned host memory (one DMA at link speed; the block returns to the
+        library's pool when the array dies)."""
         row1 = self.total if row1 is None else row1
-        out = np.empty(row1 - row0, dtype=np.int64)
+        big = pinned and (row1 - row0) >= (1 << 19)
+        out = _lib.pinned_empty(row1 - row0, np.int64) if big else np.empty(row1 - row0, dtype=np.int64)
         _lib.check(_lib.load().tehmm_batch_get_paths(self._h, row0, row1, ptr(out, i64p)),
                    "tehmm_batch_get_paths")
         return out
 
-    def posteriors(self, n_states=None, row0=0, row1=None):
+    def posteriors(self, n_states=None, row0=0, row1=None, pinned=True):
         n_states = self.N if n_states is None else n_states
         row1 = self.total if row1 is None else row1
-        out = np.empty((row1 - row0, n_states), dtype=np.float64)
+        big = pinned and (row1 - row0) * n_states >= (1 << 19)
+        out = (_lib.pinned_empty((row1 - row0, n_states), np.float64) if big
+               else np.empty((row1 - row0, n_states), dtype=np.float64))
         _lib.check(_lib.load().tehmm_batch_get_posteriors(self._h, row0, row1, ptr(out, f64p)),
                    "tehmm_batch_get_posteriors")
         return out
