@@ -92,6 +92,10 @@ int grid_for(int64_t work, int block, int cap = 8192) {
 }
 
 constexpr int kMaxStates = 128;
+// segment ratios on the chunk-parallel Viterbi lane passes up to this many padded states (round 2: 36)
+#ifndef TEHMM_RATIO_LANE_MAX
+#define TEHMM_RATIO_LANE_MAX 64
+#endif
 
 // padded state count: the cooperative kernels are instantiated for these sizes
 int pad_states(int N) {
@@ -955,7 +959,7 @@ static void launch_vit_fix(tehmm_batch *b, const tehmm_model *m, const IntervalT
   size_t lds = ((size_t)3 * 32 * (NT + 1) + 2 * 33 * (NT + 2) + (size_t)m->lds_rows * NT + 16) * sizeof(double);   // CPB = 32
   allow_lds(k_vit_fix<NT, false>, lds);
   allow_lds(k_vit_fix<NT, true>, lds);
-  if constexpr (NT <= 36) if (ratio) {
+  if constexpr (NT <= TEHMM_RATIO_LANE_MAX) if (ratio) {
     allow_lds(k_vit_fix<NT, true, true>, lds);
     hipLaunchKernelGGL((k_vit_fix<NT, true, true>), dim3(b->n), dim3(256), lds, st, iv, em, vc, m->N, m->lt.p,
                        m->ltT.p, m->pi.p, b->tb.p, b->last_state.p, b->vit_lp.p, b->sw.stats.p,
@@ -1166,7 +1170,7 @@ static void launch_vit_lane(tehmm_batch *b, const tehmm_model *m, const Interval
   (void)lw.d_vc.fill_async(&lw.hs_vc, 1, st);
   (void)lw.d_vi.fill_async(&lw.hs_vi, 1, st);
   const dim3 grid((n_work + 3) / 4);
-  if constexpr (NT <= 36) if (quant && ratio) {
+  if constexpr (NT <= TEHMM_RATIO_LANE_MAX) if (quant && ratio) {
     hipLaunchKernelGGL((k_vit_lane<NT, true, true>), grid, dim3(256), 0, st, iv, lg, (const VitChunks *)lw.d_vc.p,
                        (const VitItems *)lw.d_vi.p, m->N, Wu,
                        (const int *)lw.wk_g.p, (const int *)lw.wk_e.p, n_work, (const double *)lw.qtabs.p, e0,
@@ -1220,7 +1224,7 @@ static void launch_emis_gain_lane(tehmm_batch *b, const tehmm_model *m, const In
                                   int CS, int Wu, bool ratio, hipStream_t st) {
   LaneWork &lw = b->lw;
   const size_t lds = (size_t)em.lds_rows * NT * sizeof(double);
-  if constexpr (NT <= 36) if (ratio) {
+  if constexpr (NT <= TEHMM_RATIO_LANE_MAX) if (ratio) {
     allow_lds(k_emis_gain_lane<NT, true>, lds);
     hipLaunchKernelGGL((k_emis_gain_lane<NT, true>), dim3((lw.n_groups + 3) / 4), dim3(256), lds, st, iv, em,
                        lane_geom(lw), m->N, CS, Wu, (const float *)m->ltP.p, lw.B.p, lw.vgain.p,
@@ -1305,20 +1309,14 @@ static void launch_fb_lane(tehmm_batch *b, const tehmm_model *m, const IntervalT
 // Fused posterior pipeline (tehmm_fused.hip.h), one stream: forward lane pass -> forward links / runs / exact
 // chain (alpha' rows final) -> backward lane pass writing the posterior rows -> backward links / runs ->
 // [ev_mid] -> backward exact chain (posterior rows of its exact blocks).  ev_fwd: end of the forward half.
+// Index records of the fused passes (FusedTab::rixx): the track order of EmisStream's fixed schedule and, unless
+// the records of this (batch, model layout, item length, warm-up) exist already, k_fused_rowindex on `st`.
+// Depends on the observations only, so tehmm_eval_batch enqueues it ahead of the deferral behind the Viterbi
+// passes: the 3 ms of a first evaluation hide next to the emission-row kernel.
 template <int NT>
-static int launch_fused_fb(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em_in,
-                           const FbChunks &fc, int Wu, hipStream_t st, hipEvent_t ev_fwd, hipEvent_t ev_mid,
-                           bool estep = false) {
+static int fused_prepare(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, int Wu, hipStream_t st, FusedOrder &fo) {
   LaneWork &lw = b->lw;
   const LaneGeom lg = lane_geom(lw);
-  const dim3 gridm((unsigned)lw.n_groups);           // 4 tiles of 16 items per 256-thread block = one group
-  const dim3 gridc((fc.n + 255) / 256);              // one thread per chunk
-  const dim3 gridit((lw.n_items + 255) / 256);       // one thread per item
-  const dim3 gridi(std::max(1, b->n));
-  const char *er = std::getenv("TEHMM_FB_RUNS");
-  const int extend = (er && std::atoi(er) == 0) ? 0 : 1;
-  // processing order of the tracks: those served from the global table (L2) first, then the LDS-staged ones
-  FusedOrder fo;
   std::memset(&fo, 0, sizeof(fo));
   fo.K = m->K;
   fo.KP = b->KP;
@@ -1358,6 +1356,23 @@ static int launch_fused_fb(tehmm_batch *b, const tehmm_model *m, const IntervalT
     lw.rix_L = lw.L;
     lw.rix_Wu = Wu;
   }
+  return TEHMM_OK;
+}
+
+template <int NT>
+static int launch_fused_fb(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em_in,
+                           const FbChunks &fc, int Wu, hipStream_t st, hipEvent_t ev_fwd, hipEvent_t ev_mid,
+                           bool estep = false) {
+  LaneWork &lw = b->lw;
+  const LaneGeom lg = lane_geom(lw);
+  const dim3 gridm((unsigned)lw.n_groups);           // 4 tiles of 16 items per 256-thread block = one group
+  const dim3 gridc((fc.n + 255) / 256);              // one thread per chunk
+  const dim3 gridit((lw.n_items + 255) / 256);       // one thread per item
+  const dim3 gridi(std::max(1, b->n));
+  const char *er = std::getenv("TEHMM_FB_RUNS");
+  const int extend = (er && std::atoi(er) == 0) ? 0 : 1;
+  FusedOrder fo;
+  if (int rcp = fused_prepare<NT>(b, m, iv, Wu, st, fo)) return rcp;
   FusedTab ft;
   ft.rixx = lw.rix.p;
   ft.ptab = m->ptab.p;
@@ -1578,7 +1593,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   const bool vit = flags & TEHMM_EVAL_VITERBI, postr = flags & TEHMM_EVAL_POSTERIOR;
   // segment ratios: the chunk-parallel Viterbi path takes them in its lane = item form only (finite
   // self-transitions, NP <= 36, the fused P0 pass); otherwise the sequential kernels
-  bool vspec = vit && spec_ok && (!ratio || (ratio_lane_ok(m) && m->NP <= 36));
+  bool vspec = vit && spec_ok && (!ratio || (ratio_lane_ok(m) && m->NP <= TEHMM_RATIO_LANE_MAX));
   const bool fspec = postr && spec_ok;
   if (vspec || fspec) {
     rc = spec_prepare(b, m, CS);
@@ -1779,6 +1794,15 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     return TEHMM_OK;
   };
   if (postr && defer_post) enqueue_emission();      // the emission rows do not wait (17 ms next to P0)
+  if (postr && defer_post && flane && fused_fb) {
+    // neither do the index records of the fused passes: they only read the observations
+    int rcp = TEHMM_OK;
+    FusedOrder fo_unused;
+#define CALL(NT_) rcp = fused_prepare<NT_>(b, m, iv, WuF, b->sP, fo_unused)
+    TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+    if (rcp) return rcp;
+  }
   if (postr && !defer_post) {
     enqueue_emission();
     rc = enqueue_posterior();
@@ -2473,11 +2497,33 @@ void launch_estep(const tehmm_model *m, const IntervalTab &iv, const EmisTab &em
 // Track partition of the reduction kernels (tehmm_estep.hip.h): tracks of at most TEHMM_ESTEP_SMALL rows are
 // packed into 16-row tiles for the one-hot product on the matrix cores, the others into LDS histogram groups of
 // at most `cap_rows` rows (first fit, decreasing).
-#define TEHMM_ESTEP_SMALL 40
+// The two histogram kernels run side by side on different pipes, so the split balances them (measured on MI355X,
+// per CU, 16-item tile and step: ~12 ns per matrix instruction = 4 NTILE x 12 ns per 16-row tile next to the
+// 4 NTILE^2 instructions of the xi product; ~21 ns per ds_add_f64 = KS x 21 ns per track): tracks in ascending
+// row order go to the matrix cores while that lowers max(matrix time, LDS time).  TEHMM_ESTEP_SMALL overrides
+// (largest track, in rows, that takes the one-hot product).
+static int estep_small_threshold(const tehmm_model *m) {
+  if (const char *sm = std::getenv("TEHMM_ESTEP_SMALL")) return std::atoi(sm);
+  const int KS = m->NP / 4, P = (KS + 1) / 2, PQ = (P + 3) / 4;
+  const int NTILE = 2 * PQ - ((32 * (PQ - 1) + 4 < m->NP) ? 0 : 1);
+  std::vector<int> rows(m->rowcnt, m->rowcnt + m->K);
+  std::sort(rows.begin(), rows.end());
+  double best = 1e300;
+  int best_thr = 0, small_rows = 0;
+  for (int k = 0; k <= m->K; ++k) {                 // the k smallest tracks on the matrix cores
+    if (k > 0) small_rows += rows[(size_t)k - 1];
+    if (small_rows > TEHMM_ESTEP_MAXRT * 16) break;
+    const double t_mfma = 12.0 * (4.0 * NTILE * NTILE + 4.0 * NTILE * ((small_rows + 15) / 16));
+    const double t_lds = 21.0 * KS * (m->K - k);
+    const double t = std::max(t_mfma, t_lds) + 0.05 * (t_mfma + t_lds);
+    if (t < best) { best = t; best_thr = k > 0 ? rows[(size_t)k - 1] : 0; }
+  }
+  return best_thr;
+}
+
 static void estep_build_groups(const tehmm_model *m, int cap_rows, EstepGroups &eg) {
   std::memset(&eg, 0, sizeof(eg));
-  const char *sm = std::getenv("TEHMM_ESTEP_SMALL");
-  const int small = sm ? std::atoi(sm) : TEHMM_ESTEP_SMALL;
+  const int small = estep_small_threshold(m);
   std::vector<int> big;
   int row = 0;
   for (int i = 0; i < TEHMM_ESTEP_MAXRT * 16; ++i) eg.rt_info[i] = -1;

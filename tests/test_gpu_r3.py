@@ -302,3 +302,47 @@ def test_fused_estep_impossible_rows_poison_like_the_reference(monkeypatch):
     hb.close()
     assert np.isnan(lp) and np.isnan(trans).all() and np.isnan(st).any()
     assert np.isfinite(ilp[0]) and np.isnan(ilp[1])
+
+
+# ------------------------------------------------------------------ segment ratios on the lane path, 37 <= N <= 63
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("N,env", [
+    (41, {"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "64"}),
+    (50, {"TEHMM_SPEC_CHUNK": "512", "TEHMM_LANE_SUB": "128"}),
+    (63, {"TEHMM_SPEC_CHUNK": "256", "TEHMM_LANE_SUB": "64"}),
+    (63, {"TEHMM_SPEC_CHUNK": "1024"}),
+])
+def test_ratio_decode_37_to_63_states_chunk_parallel(monkeypatch, N, env):
+    """Decode on a segmented table (_hmm.pyx:229-247, from-state-0 quirk Q4) for 37..63 states: round 2 sent these to
+    the sequential kernel; the quantised lane pass, its P0 and the exact chain now exist with ratios up to 64 padded
+    states.  Paths and scores bit-exact against the oracle, and chunks really are jumped over."""
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    from oracle import oracle
+    for k in ("TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_LANE_WARMUP", "TEHMM_LANE_VIT", "TEHMM_LANE_P0", "TEHMM_VIT_RUNS"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    model = synth.make_model(N, seed=11 + N)
+    lens = [1, 300, 5000, 60000, 150000] if env["TEHMM_SPEC_CHUNK"] != "1024" else [700, 90000, 300000]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    T = int(offs[-1])
+    obs = synth.sample_obs(model, T, seed=N, missing=0.02)
+    rs = np.random.RandomState(N)
+    ratios = synth.random_ratios(T, seed=N)
+    ratios[rs.rand(T) < 0.4] = 1.0
+    idx = rs.randint(0, T, size=max(1, T // 500))
+    ratios[idx] = rs.randint(200, 5000, size=idx.size).astype(np.float64) / 20.0
+    ratios = np.ascontiguousarray(ratios)
+    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, 1.0, model.symbols_per_track)
+    hb = HipBatch(obs, offs, ratios)
+    res = hm.eval(hb, viterbi=True, posterior=False, use_ratios=True)
+    paths = hb.paths()
+    tm = hb.timing()
+    hb.close()
+    assert tm.get("count:viterbi_chunk_jumps", 0) > 0
+    for i in range(len(lens)):
+        a, b = int(offs[i]), int(offs[i + 1])
+        lp_o, path_o = oracle.decode(obs[a:b], model.log_probs, model.log_startprob, model.log_transmat, 1.0, ratios[a:b])
+        assert_array_equal(paths[a:b], path_o)
+        assert res["viterbi_logprob"][i] == lp_o
