@@ -178,6 +178,20 @@ def verify_intervals(model, hb, obs, offs, res, n_threads=2):
             "posterior_max_rel_err": worst, "verify_s": time.perf_counter() - t0}
 
 
+def cpu_baseline_estep(n_seq=4, per_seq=100_000):
+    """The oracle's E-step (forward, backward, xi log-sum, emission statistics per sequence: basehmm.py:504-523 as
+    restated in oracle/) on a bounded sample of the config-4 workload, one core (the reference is single-threaded)."""
+    from oracle import oracle
+    from tehmm_amd import synth
+    m4 = synth.make_model(N_STATES, synth.CONFIG4_SYMBOLS, synth.CONFIG4_GAUSSIAN, seed=0)
+    seqs = [synth.sample_obs(m4, per_seq, seed=300 + i) for i in range(n_seq)]
+    t0 = time.perf_counter()
+    oracle.estep(seqs, m4.log_probs, m4.log_startprob, m4.log_transmat, 1.0, None)
+    dt = time.perf_counter() - t0
+    return {"value": float(n_seq * per_seq) / dt, "unit": "positions/s per EM iteration", "cores": 1, "kind": "port",
+            "sample": "%d sequences x %d positions, E-step statistics, 1 thread, %.1f s" % (n_seq, per_seq, dt)}
+
+
 def time_eval(hm, hb, torch, steps=1, **kw):
     hm.eval(hb, **kw)                        # warm-up (allocates result buffers / workspaces)
     torch.cuda.synchronize()
@@ -284,7 +298,8 @@ def run_eval(args, rank, world, local_rank):
                 "forward_pass": 2 * N * N, "backward_posterior_pass": 2 * N * N}
         traffic = None
         stage_hbm = None
-        tpath = next((p for p in (os.path.join(ROOT, "profiles", "r02_traffic.json"),
+        tpath = next((p for p in (os.path.join(ROOT, "profiles", "r03_traffic.json"),
+                                  os.path.join(ROOT, "profiles", "r02_traffic.json"),
                                   os.path.join(ROOT, "profiles", "r01_traffic.json")) if os.path.exists(p)), None)
         if tpath:     # HBM bytes per position measured with rocprofv3 --pmc (see file)
             tjson = json.load(open(tpath))
@@ -450,11 +465,22 @@ def extras(args, model, hm, hb, obs, offs, lens, device, torch, mk_model):
     l5 = np.full(20, 100_000, dtype=np.int64)
     o5 = np.concatenate([[0], np.cumsum(l5)]).astype(np.int64)
     ob = gen_obs_torch(m5, l5, seed=33, device=device)
-    r5 = torch.full((int(o5[-1]),), 0.2, dtype=torch.float64, device=device)
+    # segment ratios on both sides of 1 (lengths ~ 1 + Geometric(1 / 20) capped at 100, effective length 20)
+    g5 = torch.Generator(device=device)
+    g5.manual_seed(6)
+    sl5 = torch.clamp(1 + torch.floor(torch.log1p(-torch.rand(int(o5[-1]), generator=g5, device=device, dtype=torch.float64))
+                                      / np.log(1 - 1 / 20.0)), max=100.0)
+    r5 = (sl5 / 20.0).contiguous()
     hm5 = mk_model(m5)
     hb5 = HipBatch(ob.data_ptr(), o5, ratios=r5.data_ptr(), device_ptrs=True, K=K)
     d = time_eval(hm5, hb5, torch, viterbi=True, posterior=True, use_ratios=True)
-    ex["config5_100_states_segmented"] = rate(int(o5[-1]), d, positions=int(o5[-1]))
+    ex["config5_100_states_segmented"] = rate(int(o5[-1]), d, positions=int(o5[-1]), kernel_ms=hb5.timing())
+    # the two halves: the posterior runs item-parallel on the matrix cores (tehmm_wide.hip.h), the exact Viterbi with
+    # segment ratios is still ONE four-wave workgroup per interval at this state count
+    d = time_eval(hm5, hb5, torch, viterbi=False, posterior=True, use_ratios=True)
+    ex["config5_100_states_posterior_only"] = rate(int(o5[-1]), d, positions=int(o5[-1]), kernel_ms=hb5.timing())
+    d = time_eval(hm5, hb5, torch, viterbi=True, posterior=False, use_ratios=True)
+    ex["config5_100_states_viterbi_only"] = rate(int(o5[-1]), d, positions=int(o5[-1]))
     hb5.close()
     hm5.close()
     del ob, r5
@@ -500,12 +526,13 @@ def em_iterations(mb, n_iter, device, torch, dist):
         dist.barrier()
     d = (time.perf_counter() - t1) / n_iter
     n = int(o4[-1])
+    stage_ms = {k: v for k, v in hb4.timing().items() if not k.startswith("count:")}
     hb4.close()
     st.close()
     hm4.close()
     del ob
     return {"value": float(n) / d, "unit": "positions/s per EM iteration", "ms_per_iteration": d * 1e3,
-            "positions": n, "chunks": int(n_chunks), "logprob_per_iteration": lps,
+            "positions": n, "chunks": int(n_chunks), "logprob_per_iteration": lps, "estep_stage_ms": stage_ms,
             "alg_bytes_per_position": m4.n_tracks, "hbm_GBps_algorithmic": m4.n_tracks * float(n) / d / 1e9}
 
 
@@ -537,8 +564,14 @@ def run_estep(args, rank, world, local_rank):
                             "achieved": r["alg_bytes_per_position"] * r["positions"] / d / 1e9,
                             "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": r["alg_bytes_per_position"] * r["positions"] / d / 1e9 / HBM_PEAK_GBPS,
-                            "traffic": None},
+                            "traffic": None,
+                            # what really binds: fp64 matrix + vector issue; forward + backward + xi = 3 x 2 N^2 flop
+                            "f64": {"achieved": 6.0 * N_STATES * N_STATES * r["positions"] / d / 1e12,
+                                    "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s"}},
+               "estep_stage_ms": r["estep_stage_ms"],
                "logprob_per_iteration": r["logprob_per_iteration"]}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_estep()
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

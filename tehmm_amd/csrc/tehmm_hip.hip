@@ -7,6 +7,7 @@
 #include "tehmm_aux.hip.h"
 #include "tehmm_fused.hip.h"
 #include "tehmm_estep.hip.h"
+#include "tehmm_wide.hip.h"
 
 #include <algorithm>
 #include <atomic>
@@ -196,8 +197,19 @@ struct LaneWork {
   VitItems hs_vi;
 };
 
+// item bookkeeping and buffers of the chunk-parallel posterior for 64 <= N <= 128 (tehmm_wide.hip.h)
+struct WideWork {
+  int L = 0, NPW = 0, n_items = 0, n_groups = 0, wu_ok = 0;
+  uint64_t wu_model = 0, wu_version = 0;
+  DBuf<int> item_iv, flags;
+  DBuf<int64_t> item_t0, ifirst;
+  DBuf<double> E, ms, pre_f, end_f, pre_b, end_b, SL, lr;
+  DBuf<float> AL;
+};
+
 struct tehmm_batch {
   EstepWork ew;
+  WideWork ww;
   SpecWork sw;
   LaneWork lw;
   int n = 0, K = 0, KP = 0;
@@ -1498,6 +1510,112 @@ static void launch_fb_fix(tehmm_batch *b, const tehmm_model *m, const IntervalTa
 #endif
 
 
+
+// ---- chunk-parallel posterior for 64 <= N <= 128 (tehmm_wide.hip.h) ---------------------------------------------
+template <int NPW>
+static void launch_wide_passes(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const LaneGeom &lg, int Wu,
+                               hipStream_t st, hipEvent_t mid) {
+  WideWork &w = b->ww;
+  const size_t lds = WideGeom<NPW>::FRAG_BYTES;
+  allow_lds(k_wide_fwd<NPW>, lds);
+  allow_lds(k_wide_bwd<NPW>, lds);
+  const dim3 grid((unsigned)std::max(1, w.n_groups));
+  hipLaunchKernelGGL((k_wide_fwd<NPW>), grid, dim3(256), lds, st, iv, lg, m->N, m->NP, Wu, (const double *)m->A.p,
+                     (const double *)m->pi.p, (const double *)w.E.p, (const double *)w.ms.p, w.AL.p, w.pre_f.p, w.end_f.p,
+                     w.SL.p);
+  (void)hipEventRecord(mid, st);
+  hipLaunchKernelGGL((k_wide_bwd<NPW>), grid, dim3(256), lds, st, iv, lg, m->N, m->NP, Wu, (const double *)m->A.p,
+                     (const double *)w.E.p, (const float *)w.AL.p, b->post.p, w.pre_b.p, w.end_b.p);
+}
+
+// *done = true: posteriors and forward log-likelihoods of the batch are in place; false: the caller runs the
+// sequential kernels (short batches, a link that does not verify within the longest warm-up, impossible rows)
+static int posterior_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em, hipStream_t st,
+                             hipEvent_t mid, bool *done) {
+  *done = false;
+  const char *ws = std::getenv("TEHMM_WIDE_CP");
+  if (ws && std::atoi(ws) == 0) return TEHMM_OK;
+  if (m->N < 64 || m->N > 128 || b->total < 4096) return TEHMM_OK;
+  static const int sizes[] = {80, 96, 112, 128};
+  int NPW = 128;
+  for (int sz : sizes)
+    if (m->N <= sz) { NPW = sz; break; }
+  WideWork &w = b->ww;
+  // item length: enough items to give every SIMD a tile (1024 tiles of 16 items), 64 <= L <= 512, multiple of 32
+  int L = (int)std::min<int64_t>(512, std::max<int64_t>(64, (b->total / (16 * 1024) + 31) & ~31));
+  if (const char *ls = std::getenv("TEHMM_WIDE_SUB")) L = std::max(32, (std::atoi(ls) + 31) & ~31);
+  if (w.L != L || w.NPW != NPW || !w.item_iv.p) {
+    std::vector<int> h_iv;
+    std::vector<int64_t> h_t0, h_first((size_t)b->n + 1, 0);
+    for (int i = 0; i < b->n; ++i) {
+      h_first[(size_t)i] = (int64_t)h_iv.size();
+      for (int64_t t0 = 0; t0 < b->h_len[(size_t)i]; t0 += L) {
+        h_iv.push_back(i);
+        h_t0.push_back(t0);
+      }
+    }
+    h_first[(size_t)b->n] = (int64_t)h_iv.size();
+    w.L = L;
+    w.NPW = NPW;
+    w.n_items = (int)h_iv.size();
+    w.n_groups = (w.n_items + 63) / 64;
+    w.wu_ok = 0;
+    HIPCHK(w.item_iv.upload(h_iv.data(), h_iv.size()));
+    HIPCHK(w.item_t0.upload(h_t0.data(), h_t0.size()));
+    HIPCHK(w.ifirst.upload(h_first.data(), h_first.size()));
+    const size_t ni = (size_t)std::max(1, w.n_groups) * 64;
+    HIPCHK(w.E.alloc((size_t)b->total * NPW + 1));
+    HIPCHK(w.ms.alloc((size_t)b->total + 1));
+    HIPCHK(w.AL.alloc(ni * L * (NPW / 4) * 4));
+    for (DBuf<double> *d : {&w.pre_f, &w.end_f, &w.pre_b, &w.end_b}) HIPCHK(d->alloc(ni * NPW));
+    HIPCHK(w.SL.alloc(ni));
+    HIPCHK(w.lr.alloc(ni));
+    HIPCHK(w.flags.alloc(4));
+  }
+  LaneGeom lg;
+  lg.item_iv = w.item_iv.p; lg.item_t0 = w.item_t0.p; lg.ifirst = w.ifirst.p;
+  lg.n_items = w.n_items; lg.n_groups = w.n_groups; lg.L = L;
+  const EmisTab emg = without_lds_tables(em);
+  HIPCHK(hipMemsetAsync(w.flags.p, 0, 4 * sizeof(int), st));
+  hipLaunchKernelGGL(k_wide_emis, dim3((w.n_items + 3) / 4), dim3(256), 0, st, iv, emg, lg, m->N, NPW, w.E.p, w.ms.p, w.flags.p);
+  // warm-up: 128 positions, doubled until every link verifies (it may exceed the item length: the passes read the
+  // emission rows of the interval, not of the item); beyond 1024 the sequential kernels take over
+  constexpr int kWuMax = 1024;
+  int Wu = 128;
+  if (const char *wus = std::getenv("TEHMM_LANE_WARMUP")) Wu = std::min(kWuMax, std::max(1, std::atoi(wus)));
+  else if (w.wu_ok > 0 && w.wu_model == m->uid && w.wu_version == m->version) Wu = w.wu_ok;
+  for (;;) {
+    switch (NPW) {
+      case 80: launch_wide_passes<80>(b, m, iv, lg, Wu, st, mid); break;
+      case 96: launch_wide_passes<96>(b, m, iv, lg, Wu, st, mid); break;
+      case 112: launch_wide_passes<112>(b, m, iv, lg, Wu, st, mid); break;
+      default: launch_wide_passes<128>(b, m, iv, lg, Wu, st, mid); break;
+    }
+    hipLaunchKernelGGL(k_wide_links, dim3((w.n_items + 255) / 256), dim3(256), 0, st, iv, lg, m->N, NPW,
+                       (const double *)w.pre_f.p, (const double *)w.end_f.p, (const double *)w.pre_b.p,
+                       (const double *)w.end_b.p, w.lr.p, w.flags.p);
+    HIPCHK(hipGetLastError());
+    int flags[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(flags, w.flags.p, sizeof(flags), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (std::getenv("TEHMM_SPEC_DEBUG"))
+      std::fprintf(stderr, "[tehmm wide] NPW %d L %d Wu %d: impossible rows in %d items, failed links %d of %d items\n", NPW, L, Wu,
+                   flags[0], flags[1], w.n_items);
+    if (flags[0] > 0) return TEHMM_OK;                 // impossible rows: the sequential kernels own their semantics
+    if (flags[1] == 0) break;
+    if (Wu >= kWuMax) return TEHMM_OK;                 // does not forget: sequential kernels
+    Wu = std::min(kWuMax, 2 * Wu);
+    HIPCHK(hipMemsetAsync(w.flags.p, 0, 4 * sizeof(int), st));
+  }
+  w.wu_ok = Wu;
+  w.wu_model = m->uid;
+  w.wu_version = m->version;
+  hipLaunchKernelGGL(k_wide_loglik, dim3((b->n + 63) / 64), dim3(64), 0, st, iv, lg, m->N, NPW, (const double *)w.end_f.p,
+                     (const double *)w.SL.p, (const double *)w.lr.p, b->fwd_lp.p);
+  *done = true;
+  return TEHMM_OK;
+}
+
 // Forward / backward warm-up of the lane passes: TEHMM_LANE_WARMUP if set, else measured on this batch's own
 // observations by k_fb_probe (96 windows per direction; tehmm_spec.hip.h) -- the longest forgetting time seen,
 // plus a fifth, at least 32 and at most the item length.  TEHMM_LANE_PROBE=0: the round-2 constant 64.
@@ -1721,6 +1839,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       (void)hipEventRecord(b->ev[eP + 4], st);
     }
   };
+  bool wide_cp = false;                             // the chunk-parallel posterior for 64 <= N <= 128 ran
   auto enqueue_posterior = [&]() -> int {
     hipStream_t st = b->sP;
     (void)hipEventRecord(b->ev[10], st);            // start of the passes (behind any deferral wait)
@@ -1788,8 +1907,16 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
                          b->total, m->N, b->post.p, b->beta.p);
       hipLaunchKernelGGL(k_poison_dead, dim3(64, std::min(b->n, 1024)), dim3(256), 0, st, iv, b->dead.p, m->N, b->post.p,
                          b->fwd_lp.p);
-    } else if (SPL == 1) launch_posterior<1>(b, m, iv, em, st, b->ev[eP + 1]);
-    else launch_posterior<2>(b, m, iv, em, st, b->ev[eP + 1]);
+    } else {
+      bool wide_done = false;
+      rc = posterior_wide_cp(b, m, iv, em, st, b->ev[eP + 1], &wide_done);
+      if (rc) return rc;
+      wide_cp = wide_done;
+      if (!wide_done) {
+        if (SPL == 1) launch_posterior<1>(b, m, iv, em, st, b->ev[eP + 1]);
+        else launch_posterior<2>(b, m, iv, em, st, b->ev[eP + 1]);
+      }
+    }
     (void)hipEventRecord(b->ev[eP + 2], st);
     return TEHMM_OK;
   };
@@ -2076,6 +2203,10 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     b->tms.push_back((double)st[2]);
     b->tnames.push_back("count:backward_chunk_jumps");
     b->tms.push_back((double)st[3]);
+  }
+  if (wide_cp) {
+    b->tnames.push_back("count:wide_chunk_parallel_warmup");
+    b->tms.push_back((double)b->ww.wu_ok);
   }
   if (vspec) {
     // counters (not times): 64-position blocks the exact chain ran / chunks it could jump over
@@ -2497,28 +2628,16 @@ void launch_estep(const tehmm_model *m, const IntervalTab &iv, const EmisTab &em
 // Track partition of the reduction kernels (tehmm_estep.hip.h): tracks of at most TEHMM_ESTEP_SMALL rows are
 // packed into 16-row tiles for the one-hot product on the matrix cores, the others into LDS histogram groups of
 // at most `cap_rows` rows (first fit, decreasing).
-// The two histogram kernels run side by side on different pipes, so the split balances them (measured on MI355X,
-// per CU, 16-item tile and step: ~12 ns per matrix instruction = 4 NTILE x 12 ns per 16-row tile next to the
-// 4 NTILE^2 instructions of the xi product; ~21 ns per ds_add_f64 = KS x 21 ns per track): tracks in ascending
-// row order go to the matrix cores while that lowers max(matrix time, LDS time).  TEHMM_ESTEP_SMALL overrides
-// (largest track, in rows, that takes the one-hot product).
-static int estep_small_threshold(const tehmm_model *m) {
+// Where the split lies (measured, config-4 model, 50 Mb, reduce stage): tracks of <= 9 rows on the matrix cores
+// 21.6 ms, <= 21 rows 17.2, <= 31 (all ten small tracks) 16.3 -- a 16-row tile costs 12 matrix instructions per
+// 16-item tile and step (~9 ns per row and CU), a track in LDS ~190-270 ns (nine ds_add_f64 at ~1 lane per cycle,
+// more when items share a symbol), and the LDS kernel's workgroups do not share a CU with the 416-register waves
+// of the one-hot kernel, so the two add up rather than overlap: break-even near 40 rows.
+// TEHMM_ESTEP_SMALL overrides (largest track, in rows, that takes the one-hot product).
+#define TEHMM_ESTEP_SMALL_DEFAULT 40
+static int estep_small_threshold(const tehmm_model *) {
   if (const char *sm = std::getenv("TEHMM_ESTEP_SMALL")) return std::atoi(sm);
-  const int KS = m->NP / 4, P = (KS + 1) / 2, PQ = (P + 3) / 4;
-  const int NTILE = 2 * PQ - ((32 * (PQ - 1) + 4 < m->NP) ? 0 : 1);
-  std::vector<int> rows(m->rowcnt, m->rowcnt + m->K);
-  std::sort(rows.begin(), rows.end());
-  double best = 1e300;
-  int best_thr = 0, small_rows = 0;
-  for (int k = 0; k <= m->K; ++k) {                 // the k smallest tracks on the matrix cores
-    if (k > 0) small_rows += rows[(size_t)k - 1];
-    if (small_rows > TEHMM_ESTEP_MAXRT * 16) break;
-    const double t_mfma = 12.0 * (4.0 * NTILE * NTILE + 4.0 * NTILE * ((small_rows + 15) / 16));
-    const double t_lds = 21.0 * KS * (m->K - k);
-    const double t = std::max(t_mfma, t_lds) + 0.05 * (t_mfma + t_lds);
-    if (t < best) { best = t; best_thr = k > 0 ? rows[(size_t)k - 1] : 0; }
-  }
-  return best_thr;
+  return TEHMM_ESTEP_SMALL_DEFAULT;
 }
 
 static void estep_build_groups(const tehmm_model *m, int cap_rows, EstepGroups &eg) {

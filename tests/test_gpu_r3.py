@@ -346,3 +346,76 @@ def test_ratio_decode_37_to_63_states_chunk_parallel(monkeypatch, N, env):
         lp_o, path_o = oracle.decode(obs[a:b], model.log_probs, model.log_startprob, model.log_transmat, 1.0, ratios[a:b])
         assert_array_equal(paths[a:b], path_o)
         assert res["viterbi_logprob"][i] == lp_o
+
+
+# ------------------------------------------------------------------ chunk-parallel posterior, 64 <= N <= 128
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("N,kw,normalize", [
+    (64, {}, 1.0), (77, {}, 1.0), (100, {}, 1.0), (128, {}, 1.0),
+    (100, dict(stay=0.995), 1.0),               # sticky: the warm-up has to grow until every link verifies
+    (100, dict(sparse=0.5), 1.0),               # -1e100 transitions
+    (90, {}, 0.3),                              # --emFac
+])
+def test_wide_posterior_chunk_parallel_vs_oracle(monkeypatch, N, kw, normalize):
+    """BaseHMM.score_samples for the model sizes of BASELINE configs[4] (64..128 states) on the item-parallel
+    matrix-core passes of tehmm_wide.hip.h: posteriors and forward log-likelihoods against the CPU oracle on
+    ragged intervals (one-row, shorter than an item, not a multiple of the item length), 1e-6 -- and the
+    same batch on the sequential kernels (TEHMM_WIDE_CP=0)."""
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    from oracle import oracle
+    for k in ("TEHMM_WIDE_CP", "TEHMM_WIDE_SUB", "TEHMM_LANE_WARMUP"):
+        monkeypatch.delenv(k, raising=False)
+    model = synth.make_model(N, synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=3 + N, **kw)
+    rs = np.random.RandomState(N)
+    lens = [int(x) for x in rs.randint(9000, 30000, size=4)] + [1, 70, 1500, 64, 129]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = synth.sample_obs(model, int(offs[-1]), seed=5, missing=0.02)
+    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, normalize, model.symbols_per_track)
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TEHMM_WIDE_CP", mode)
+        hb = HipBatch(obs, offs)
+        res = hm.eval(hb, viterbi=False, posterior=True)
+        tm = hb.timing()
+        got[mode] = (res["forward_logprob"].copy(), np.array(hb.posteriors()))
+        hb.close()
+        assert ("count:wide_chunk_parallel_warmup" in tm) == (mode == "1")
+    _, _, flp_o, post_o = oracle.eval_batch(obs, offs, model.log_probs, model.log_startprob, model.log_transmat,
+                                            normalize, None, n_threads=8)
+    for mode in ("1", "0"):
+        flp, post = got[mode]
+        assert_allclose(flp, flp_o, rtol=1e-9)
+        assert_allclose(post, post_o, rtol=RTOL, atol=1e-15)
+    worst = float(np.max(np.abs(got["1"][1] - post_o) / post_o))
+    print("wide posterior N=%d: max rel error %.3g" % (N, worst))
+    assert worst <= 3e-7
+
+
+def test_wide_posterior_impossible_rows_fall_back(monkeypatch):
+    """Rows no state can emit (leading ones: quirk Q9; later ones: NaN lattices) are the sequential kernels' business:
+    the chunk-parallel path must notice them and step aside, results equal to the sequential run bit for bit."""
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    monkeypatch.delenv("TEHMM_WIDE_CP", raising=False)
+    model = synth.make_model(70, (3, 5, 4), (), seed=21)
+    lp3 = model.log_probs.copy()
+    lp3[1, :, 2] = -np.inf
+    lens = [6000, 5000]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = synth.sample_obs(model, int(offs[-1]), seed=6)
+    obs[obs[:, 1] == 2, 1] = 1
+    obs[0:3, 1] = 2                             # leading impossible rows of the first interval (zeroed, Q9)
+    obs[8000, 1] = 2                            # inside the second interval: NaN from there on
+    hm = HipModel(model.log_transmat, model.log_startprob, lp3, 1.0, model.symbols_per_track)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TEHMM_WIDE_CP", mode)
+        hb = HipBatch(obs, offs)
+        res = hm.eval(hb, viterbi=False, posterior=True)
+        assert "count:wide_chunk_parallel_warmup" not in hb.timing()
+        out[mode] = (res["forward_logprob"].copy(), np.array(hb.posteriors()))
+        hb.close()
+    assert_array_equal(out["1"][0], out["0"][0])
+    assert_array_equal(out["1"][1], out["0"][1])
+    assert np.isfinite(out["1"][0][0])

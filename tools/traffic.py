@@ -10,7 +10,8 @@ STAGE = [("k_emis_gain_lane", "emission_rows"), ("k_emis_lane", "emission_rows")
          ("k_vit_spec", "viterbi_speculate"), ("k_vit_fix", "viterbi"), ("k_vit_coop", "viterbi"), ("k_tb_", "traceback"),
          ("k_fused_fwd", "forward_pass"), ("k_fb_fix<36, 0", "forward_pass"), ("k_fused_bwd", "backward_posterior_pass"),
          ("k_fb_fix<36, 1", "backward_chain"), ("k_fb_itemlinks", "links"), ("k_fb_stitch", "links"), ("k_fb_runs", "links"),
-         ("k_fused_rowindex", "setup_once"), ("k_repack_obs", "setup_once"), ("k_poison_dead", "backward_chain"),
+         ("k_fused_rowindex", "forward_pass"), ("k_repack_obs", "setup_once"), ("k_poison_dead", "backward_chain"),
+         ("k_fb_probe", "forward_pass"), ("k_estep_xi", "estep_reduce"), ("k_estep_hist", "estep_reduce"),
          ("k_fb_lane", "forward_backward_speculate"), ("k_combine_lane", "posterior_combine")]
 
 
