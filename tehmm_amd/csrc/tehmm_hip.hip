@@ -205,6 +205,11 @@ struct WideWork {
   DBuf<int64_t> item_t0, ifirst;
   DBuf<double> E, ms, pre_f, end_f, pre_b, end_b, SL, lr;
   DBuf<float> AL;
+  // chunk-parallel exact Viterbi (k_vit_wide_spec / k_vit_wide_fix)
+  DBuf<double> BL;                 // log emission rows [internal position][128]
+  DBuf<int> wk_c, wk_e;            // work lists: 8 chunks of one binade per workgroup
+  std::vector<int> h_wkc, h_wke, h_e;
+  std::vector<double> h_gain;
 };
 
 struct tehmm_batch {
@@ -1616,6 +1621,113 @@ static int posterior_wide_cp(tehmm_batch *b, const tehmm_model *m, const Interva
   return TEHMM_OK;
 }
 
+
+// ---- chunk-parallel exact Viterbi for 64 <= N <= 128 (tehmm_wide.hip.h) -------------------------------------------
+// *done = true: traceback bytes, last states and scores of the batch are in place (the generic traceback follows);
+// false: the caller runs the sequential kernels
+static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em, bool ratio,
+                           hipStream_t st, bool *done) {
+  *done = false;
+  const char *ws = std::getenv("TEHMM_WIDE_VIT");
+  if (ws && std::atoi(ws) == 0) return TEHMM_OK;
+  const int CS = spec_chunk_size();
+  if (m->N < 64 || m->N > 128 || CS <= 0 || b->total < 2 * (int64_t)CS) return TEHMM_OK;
+  if (use_wide() == false || !(m->NP / 4 <= TEHMM_WIDE_QM && wide_lds_bytes(em.lds_rows, m->NP) <= 160 * 1024)) return TEHMM_OK;
+  int rc = spec_prepare(b, m, CS);
+  if (rc) return rc;
+  SpecWork &sw = b->sw;
+  WideWork &w = b->ww;
+  const int nc = sw.n_chunks;
+  if (nc <= 0) return TEHMM_OK;
+  HIPCHK(w.BL.ensure((size_t)b->total_pad * TEHMM_WIDE_S + TEHMM_WIDE_S));
+  VitChunks vc;
+  std::memset(&vc, 0, sizeof(vc));
+  vc.iv = sw.iv.p; vc.t0 = sw.t0.p; vc.first = sw.first.p; vc.n = nc; vc.CS = CS;
+  vc.e = sw.e.p; vc.gain = sw.gain.p; vc.ok = sw.ok.p; vc.wmin = sw.wmin.p; vc.rows = sw.rows.p;
+  vc.ntie = sw.ntie.p; vc.ties = sw.ties.p; vc.tierows = sw.tierows.p; vc.segmin = sw.segmin.p;
+  const EmisTab emg = without_lds_tables(em);
+  hipLaunchKernelGGL(k_wide_logrows, dim3((nc + 3) / 4), dim3(256), 0, st, iv, emg, vc, m->N, w.BL.p);
+  const size_t lds = (size_t)m->N * TEHMM_WIDE_S * sizeof(double) + 64;
+  // P0: plain gains of every chunk
+  {
+    const int nwg = (nc + 7) / 8;
+    w.h_wkc.assign((size_t)nwg * 8, -1);
+    for (int c = 0; c < nc; ++c) w.h_wkc[(size_t)c] = c;
+    w.h_wke.assign((size_t)nwg, 0);
+    HIPCHK(w.wk_c.ensure(w.h_wkc.size() + 8));
+    HIPCHK(w.wk_e.ensure(w.h_wke.size() + 8));
+    HIPCHK(hipMemcpyAsync(w.wk_c.p, w.h_wkc.data(), w.h_wkc.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    if (ratio) {
+      allow_lds(k_vit_wide_spec<false, true>, lds);
+      hipLaunchKernelGGL((k_vit_wide_spec<false, true>), dim3(nwg), dim3(512), lds, st, iv, vc, m->N, m->NP,
+                         (const double *)m->lt.p, (const double *)w.BL.p, (const double *)b->ratios.p,
+                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, b->tb.p);
+    } else {
+      allow_lds(k_vit_wide_spec<false, false>, lds);
+      hipLaunchKernelGGL((k_vit_wide_spec<false, false>), dim3(nwg), dim3(512), lds, st, iv, vc, m->N, m->NP,
+                         (const double *)m->lt.p, (const double *)w.BL.p, (const double *)nullptr,
+                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, b->tb.p);
+    }
+    w.h_gain.resize((size_t)nc);
+    HIPCHK(hipMemcpyAsync(w.h_gain.data(), sw.gain.p, (size_t)nc * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  // binades; work lists of P2: the speculated chunks sorted by binade, eight to a workgroup
+  spec_assign_binades(b, w.h_gain, w.h_e);
+  for (int c = 0; c < nc; ++c)        // seven index bits: a state may fall 2^(e - 7) behind inside a re-basing window
+    if (w.h_e[(size_t)c] != TEHMM_SPEC_NONE && w.h_e[(size_t)c] < TEHMM_SPEC_MIN_E + 1) w.h_e[(size_t)c] = TEHMM_SPEC_NONE;
+  std::vector<int> order;
+  for (int c = 0; c < nc; ++c)
+    if (w.h_e[(size_t)c] != TEHMM_SPEC_NONE) order.push_back(c);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int c2) { return w.h_e[(size_t)a] < w.h_e[(size_t)c2]; });
+  w.h_wkc.clear();
+  w.h_wke.clear();
+  for (size_t i = 0; i < order.size();) {
+    const int e = w.h_e[(size_t)order[i]];
+    w.h_wke.push_back(e);
+    int k = 0;
+    for (; k < 8 && i < order.size() && w.h_e[(size_t)order[i]] == e; ++k, ++i) w.h_wkc.push_back(order[i]);
+    for (; k < 8; ++k) w.h_wkc.push_back(-1);
+  }
+  const int nwg2 = (int)w.h_wke.size();
+  HIPCHK(hipMemcpyAsync(sw.e.p, w.h_e.data(), (size_t)nc * sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(sw.ok.p, 0, (size_t)nc * sizeof(int), st));
+  HIPCHK(hipMemsetAsync(sw.ntie.p, 0, (size_t)nc * sizeof(int), st));
+  HIPCHK(hipMemsetAsync(sw.stats.p, 0, 2 * sizeof(int), st));
+  if (nwg2 > 0) {
+    HIPCHK(w.wk_c.ensure(w.h_wkc.size() + 8));
+    HIPCHK(w.wk_e.ensure(w.h_wke.size() + 8));
+    HIPCHK(hipMemcpyAsync(w.wk_c.p, w.h_wkc.data(), w.h_wkc.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(w.wk_e.p, w.h_wke.data(), w.h_wke.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    if (ratio) {
+      allow_lds(k_vit_wide_spec<true, true>, lds);
+      hipLaunchKernelGGL((k_vit_wide_spec<true, true>), dim3(nwg2), dim3(512), lds, st, iv, vc, m->N, m->NP,
+                         (const double *)m->lt.p, (const double *)w.BL.p, (const double *)b->ratios.p,
+                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, b->tb.p);
+    } else {
+      allow_lds(k_vit_wide_spec<true, false>, lds);
+      hipLaunchKernelGGL((k_vit_wide_spec<true, false>), dim3(nwg2), dim3(512), lds, st, iv, vc, m->N, m->NP,
+                         (const double *)m->lt.p, (const double *)w.BL.p, (const double *)nullptr,
+                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, b->tb.p);
+    }
+  }
+  // the exact chain
+  const size_t ldsf = wide_lds_bytes(em.lds_rows, m->NP);
+  if (ratio) {
+    allow_lds(k_vit_wide_fix<true>, ldsf);
+    hipLaunchKernelGGL((k_vit_wide_fix<true>), dim3(b->n), dim3(256), ldsf, st, iv, em, vc, m->N, m->NP, (const double *)m->lt.p,
+                       (const double *)m->pi.p, (const double *)b->ratios.p, b->TBW, b->tb.p, b->last_state.p, b->vit_lp.p,
+                       sw.stats.p);
+  } else {
+    allow_lds(k_vit_wide_fix<false>, ldsf);
+    hipLaunchKernelGGL((k_vit_wide_fix<false>), dim3(b->n), dim3(256), ldsf, st, iv, em, vc, m->N, m->NP, (const double *)m->lt.p,
+                       (const double *)m->pi.p, (const double *)nullptr, b->TBW, b->tb.p, b->last_state.p, b->vit_lp.p,
+                       sw.stats.p);
+  }
+  *done = true;
+  return TEHMM_OK;
+}
+
 // Forward / backward warm-up of the lane passes: TEHMM_LANE_WARMUP if set, else measured on this batch's own
 // observations by k_fb_probe (96 windows per direction; tehmm_spec.hip.h) -- the longest forgetting time seen,
 // plus a fifth, at least 32 and at most the item length.  TEHMM_LANE_PROBE=0: the round-2 constant 64.
@@ -1840,6 +1952,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     }
   };
   bool wide_cp = false;                             // the chunk-parallel posterior for 64 <= N <= 128 ran
+  bool wide_vit = false;                            // ... and the chunk-parallel exact Viterbi
   auto enqueue_posterior = [&]() -> int {
     hipStream_t st = b->sP;
     (void)hipEventRecord(b->ev[10], st);            // start of the passes (behind any deferral wait)
@@ -2092,8 +2205,14 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
 #define CALL(NT_) launch_vit_coop<NT_>(b, m, iv, em, ratio, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
-    } else if (SPL == 1) launch_viterbi<1>(b, m, iv, em, ratio, st);
-    else launch_viterbi<2>(b, m, iv, em, ratio, st);
+    } else {
+      rc = viterbi_wide_cp(b, m, iv, em, ratio, st, &wide_vit);
+      if (rc) return rc;
+      if (!wide_vit) {
+        if (SPL == 1) launch_viterbi<1>(b, m, iv, em, ratio, st);
+        else launch_viterbi<2>(b, m, iv, em, ratio, st);
+      }
+    }
     (void)hipEventRecord(b->ev[eV + 1], st);
     allow_lds(k_tb_compose, 4 * TEHMM_TB_STAGE);
     allow_lds(k_tb_fill, 4 * TEHMM_TB_STAGE);
@@ -2207,6 +2326,14 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   if (wide_cp) {
     b->tnames.push_back("count:wide_chunk_parallel_warmup");
     b->tms.push_back((double)b->ww.wu_ok);
+  }
+  if (wide_vit) {
+    int st2[2] = {0, 0};
+    HIPCHK(hipMemcpy(st2, b->sw.stats.p, sizeof(st2), hipMemcpyDeviceToHost));
+    b->tnames.push_back("count:viterbi_exact_blocks");
+    b->tms.push_back((double)st2[0]);
+    b->tnames.push_back("count:viterbi_chunk_jumps");
+    b->tms.push_back((double)st2[1]);
   }
   if (vspec) {
     // counters (not times): 64-position blocks the exact chain ran / chunks it could jump over

@@ -297,4 +297,432 @@ __global__ __launch_bounds__(64) void k_wide_loglik(IntervalTab iv, LaneGeom lg,
   fwd_logprob[id] = s + log(tot);
 }
 
+
+// ==========================================================================================================
+// Chunk-parallel EXACT Viterbi for 64 <= N <= 128 (decode on BASELINE configs[4]: 100 states, segment ratios).
+// The scheme of tehmm_spec.hip.h -- P0 plain chunk gains -> host binade placement -> P2 quantised chunk pass (exact
+// integer max-plus inside a binade, the from-index in the low mantissa bits of the quantised table) -> exact chain
+// with verified jumps -> traceback -- with the lane = state mapping at two states per lane:
+//   * k_vit_wide_spec: ONE WAVE PER CHUNK, lane = to-states (lane, lane + 64).  The table of the workgroup's binade
+//     lives in LDS ([from][128] doubles, built per workgroup: eight chunks of one binade share it), the vector of
+//     the previous position reaches the lanes as scalar operands (v_readlane), so a step is N x (2 readlane,
+//     2 ds_read_b64, 2 add, 2 max) and nothing crosses lanes but the rare reductions.  Seven index bits:
+//     W = 128 (value - base) + (127 - from) u, re-based every 32 steps.
+//   * segment ratios (_hmm.pyx:229-247, quirk Q4) as in k_vit_lane: every separately rounded addend of the
+//     reference's sums is one more grid-rounded term; candidates from >= 1 share R(lt[j][j] (r - 1)) [r > 1],
+//     candidate 0 carries d0 = R(lt[j][j] r) - R(lt[j][j] (r - 1)) - [j == 0] R(lt[0][0]), a multiple of u.
+//   * k_vit_wide_fix: the exact chain = the four-wave step of k_viterbi_wide over a dynamic sequence of
+//     32-position blocks; inside a usable chunk it compares its vector with the recorded row at the first recorded
+//     position >= 12 steps into the block (V - W one constant over the live states, every value inside the binade
+//     now and -- by the chunk's P0 gain -- up to the landing position) and jumps to the next rounding tie or the
+//     chunk end with V = W + delta.  Every wave holds the whole vector, so the four waves take the decision
+//     redundantly and no extra barrier is needed.
+// Rounding ties (b or a ratio product exactly between two grid points) end a speculative segment as in
+// tehmm_spec.hip.h; the chain lands exactly on them.
+// ==========================================================================================================
+#define TEHMM_WIDE_S 128            // row stride of the wide log-row buffer and of the LDS table
+
+__device__ __forceinline__ double wide_readlane(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// log emission rows of every position, [internal position][128] (pads 0); one wave per chunk
+__global__ __launch_bounds__(256) void k_wide_logrows(IntervalTab iv, EmisTab em, VitChunks vc, int N, double *BL) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= vc.n) return;
+  const int id = vc.iv[c];
+  const int64_t T = iv.len[id], p0 = iv.pos0[id], t0 = vc.t0[c];
+  const int len = (int)min((int64_t)vc.CS, T - t0);
+  for (int s = 0; s < len; ++s) {
+    double x[2];
+    emis_log_wide(em, em.tab, p0 + t0 + s, lane, N, x);
+    double *dst = BL + (p0 + t0 + s) * TEHMM_WIDE_S;
+    dst[lane] = lane < N ? x[0] : 0.0;
+    dst[lane + 64] = lane + 64 < N ? x[1] : 0.0;
+  }
+}
+
+// block = 512: eight chunks of one binade (wk_c [8 per workgroup], -1 = none; wk_e [workgroup]); QUANT = false:
+// plain fp64 gains of every listed chunk (P0).  LDS: table [N][128] | flag
+template <bool QUANT, bool RATIO>
+__global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks vc, int N, int NP,
+                                                       const double *__restrict__ g_lt, const double *__restrict__ BL,
+                                                       const double *__restrict__ tratios, const int *__restrict__ wk_c,
+                                                       const int *__restrict__ wk_e, int TBW, uint8_t *tb) {
+  extern __shared__ double wsm[];
+  double *tq = wsm;
+  volatile int *tflag = (volatile int *)(wsm + (size_t)N * TEHMM_WIDE_S);
+  const int e = QUANT ? wk_e[blockIdx.x] : 0;
+  const double u = QUANT ? ldexp(1.0, e - 52) : 0.0;
+  const double M = QUANT ? ldexp(1.5, e) : 0.0;                 // fl(z + M) - M rounds z to the grid u
+  const double half_u = 0.5 * u;
+  const double CM = QUANT ? ldexp(1.0, e + 1) - ldexp(1.0, e - 44) : 0.0;          // 2^(e+1) - 256 u
+  const double wlim = QUANT ? -(ldexp(1.0, e) - ldexp(1.5, e - 44)) : -INFINITY;   // -(2^e - 384 u)
+  const double zlim = QUANT ? ldexp(1.0, e - 1) : INFINITY;
+  if (threadIdx.x == 0) *tflag = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < N * TEHMM_WIDE_S; i += blockDim.x) {
+    const int f = i >> 7, j = i & 127;
+    const double z = j < N ? g_lt[(size_t)f * NP + j] : -INFINITY;
+    double val = z;
+    if (QUANT) {
+      const double q = (z + M) - M;
+      if (z > -INFINITY && (fabs(z - q) == half_u || !(fabs(z) < zlim))) *tflag = 1;   // exact tie / out of range
+      val = 128.0 * q + (double)(127 - f) * u;                  // -inf stays -inf
+    }
+    tq[i] = val;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = wk_c[blockIdx.x * 8 + w];
+  if (c < 0) return;
+  const int id = vc.iv[c];
+  const int64_t p0 = iv.pos0[id], t0 = vc.t0[c];
+  const int CS = vc.CS;
+  const int len = (int)min((int64_t)CS, iv.len[id] - t0);     // (P0 also runs ragged tails; P2 only full chunks)
+  const bool live0 = lane < N, live1 = lane + 64 < N;
+  double W0 = live0 ? 0.0 : -INFINITY, W1 = live1 ? 0.0 : -INFINITY;      // QUANT: 128 x (value - base)
+  double base = 0.0;
+  int nt = 0;
+  bool bad = QUANT && *tflag != 0;
+  const double ltd0 = live0 ? g_lt[(size_t)lane * NP + lane] : 0.0;
+  const double ltd1 = live1 ? g_lt[(size_t)(lane + 64) * NP + lane + 64] : 0.0;
+  const double lt00 = g_lt[0];
+  const double lt00q = QUANT ? (lt00 + M) - M : lt00;
+  if (QUANT && RATIO && (fabs(lt00 - lt00q) == half_u || !(fabs(lt00) < zlim))) bad = true;
+  const double *bp = BL + (p0 + t0) * TEHMM_WIDE_S;
+  double bn0 = bp[lane], bn1 = bp[lane + 64];
+  for (int s = 0; s < len; ++s) {
+    const int64_t t = t0 + s;
+    const double b0 = bn0, b1 = bn1;
+    if (s + 1 < len) {
+      bn0 = bp[(int64_t)(s + 1) * TEHMM_WIDE_S + lane];
+      bn1 = bp[(int64_t)(s + 1) * TEHMM_WIDE_S + lane + 64];
+    }
+    // ---- segment-ratio terms of this position
+    bool tie = false;
+    double add0 = 0.0, add1 = 0.0;       // what every candidate from >= 1 gets (QUANT: grid-rounded, not yet x 128)
+    double dz0 = 0.0, dz1 = 0.0;         // what candidate 0 gets on top of that
+    if (RATIO) {
+      const double r = tratios[p0 + t];
+      const bool rg = r > 1.0;
+      const double za0 = ltd0 * r, za1 = ltd1 * r;                         // from == 0: lt[j][j] * r, always
+      const double zb0 = ltd0 * (r - 1.0), zb1 = ltd1 * (r - 1.0);         // from >= 1: lt[j][j] * (r - 1) if r > 1
+      if (QUANT) {
+        const double qa0 = (za0 + M) - M, qa1 = (za1 + M) - M;
+        const double qb0 = rg ? (zb0 + M) - M : 0.0, qb1 = rg ? (zb1 + M) - M : 0.0;
+        tie = tie || (live0 && (fabs(za0 - qa0) == half_u || (rg && fabs(zb0 - qb0) == half_u)));
+        tie = tie || (live1 && (fabs(za1 - qa1) == half_u || (rg && fabs(zb1 - qb1) == half_u)));
+        bad = bad || (live0 && !(fabs(za0) < zlim)) || (live1 && !(fabs(za1) < zlim));
+        add0 = qb0; add1 = qb1;
+        dz0 = (qa0 - qb0) - (lane == 0 ? lt00q : 0.0);
+        dz1 = qa1 - qb1;
+      } else {
+        add0 = rg ? zb0 : 0.0; add1 = rg ? zb1 : 0.0;
+        dz0 = (za0 - add0) - (lane == 0 ? lt00 : 0.0);
+        dz1 = za1 - add1;
+      }
+    }
+    // ---- x[j] = max_f W[f] + table[f][j]  (QUANT: the table carries 127 - f in its low bits: the first arg-max wins)
+    const double s0 = wide_readlane(W0, 0);
+    double x0 = s0 + tq[lane], x1 = s0 + tq[lane + 64];
+    if (RATIO) {
+      x0 += QUANT ? 128.0 * dz0 : dz0;
+      x1 += QUANT ? 128.0 * dz1 : dz1;
+    }
+    const int n0 = min(N, 64);
+#pragma unroll 4
+    for (int f = 1; f < n0; ++f) {
+      const double sv = wide_readlane(W0, f);
+      x0 = fmax(x0, sv + tq[f * TEHMM_WIDE_S + lane]);
+      x1 = fmax(x1, sv + tq[f * TEHMM_WIDE_S + lane + 64]);
+    }
+#pragma unroll 4
+    for (int f = 64; f < N; ++f) {
+      const double sv = wide_readlane(W1, f - 64);
+      x0 = fmax(x0, sv + tq[f * TEHMM_WIDE_S + lane]);
+      x1 = fmax(x1, sv + tq[f * TEHMM_WIDE_S + lane + 64]);
+    }
+    if (QUANT) {
+      const double bq0 = (b0 + M) - M, bq1 = (b1 + M) - M;
+      tie = tie || (live0 && fabs(b0 - bq0) == half_u) || (live1 && fabs(b1 - bq1) == half_u);
+      bad = bad | (b0 != b0);
+      if (__any(tie)) {
+        // a rounding tie at this position: close the segment (record W_{t-1}), restart from zeros; the exact chain
+        // handles position t itself
+        if (nt < TEHMM_SPEC_MAXT) {
+          if (lane == 0) vc.ties[(int64_t)c * TEHMM_SPEC_MAXT + nt] = (int)(t - t0);
+          double *tr = vc.tierows + ((int64_t)c * TEHMM_SPEC_MAXT + nt) * NP;
+          tr[lane] = live0 ? W0 * 0.0078125 + base : -INFINITY;
+          if (lane + 64 < NP) tr[lane + 64] = live1 ? W1 * 0.0078125 + base : -INFINITY;
+        }
+        ++nt;
+        W0 = live0 ? 0.0 : -INFINITY;
+        W1 = live1 ? 0.0 : -INFINITY;
+        base = 0.0;
+      } else {
+        // x = 128 (best value) + (127 - first arg-max) u, exact;  x + CM has exponent e, its low seven mantissa bits
+        // are x / u mod 128
+        const double y0 = x0 + CM, y1 = x1 + CM;
+        const unsigned l0 = (unsigned)__double2loint(y0), l1 = (unsigned)__double2loint(y1);
+        const double m0 = __hiloint2double(__double2hiint(y0), (int)(l0 & ~127u)) - CM;
+        const double m1 = __hiloint2double(__double2hiint(y1), (int)(l1 & ~127u)) - CM;
+        W0 = x0 > -INFINITY ? m0 + 128.0 * (bq0 + add0) : -INFINITY;
+        W1 = x1 > -INFINITY ? m1 + 128.0 * (bq1 + add1) : -INFINITY;
+        if (live0) tb[(p0 + t) * TBW + lane] = x0 > -INFINITY ? (uint8_t)(~l0 & 127u) : (uint8_t)0;
+        if (live1) tb[(p0 + t) * TBW + lane + 64] = x1 > -INFINITY ? (uint8_t)(~l1 & 127u) : (uint8_t)0;
+        // W must stay inside the range of the arg-max extraction
+        bad = bad | (live0 && W0 <= wlim && W0 > -INFINITY) | (live1 && W1 <= wlim && W1 > -INFINITY);
+      }
+      if ((s & (TEHMM_VROW - 1)) == TEHMM_VROW - 1) {
+        if ((s & 31) == 31) {
+          const double mx = wave_max_f64(fmax(live0 ? W0 : -INFINITY, live1 ? W1 : -INFINITY));
+          if (mx > -INFINITY) {
+            W0 -= mx;
+            W1 -= mx;
+            base += mx * 0.0078125;
+          } else {
+            bad = true;                                   // the whole vector died
+          }
+        }
+        double *row = vc.rows + ((int64_t)c * (CS / TEHMM_VROW) + s / TEHMM_VROW) * NP;
+        row[lane] = live0 ? W0 * 0.0078125 + base : -INFINITY;
+        if (lane + 64 < NP) row[lane + 64] = live1 ? W1 * 0.0078125 + base : -INFINITY;
+      }
+    } else {
+      W0 = (x0 + b0) + add0;
+      W1 = (x1 + b1) + add1;
+    }
+  }
+  if (QUANT) {
+    const unsigned long long anybad = __ballot(bad);
+    if (lane == 0) {
+      vc.ntie[c] = nt;
+      vc.ok[c] = (anybad || nt > TEHMM_SPEC_MAXT) ? 0 : 1;
+    }
+  } else {
+    const double g = wave_max_f64(fmax(live0 ? W0 : -INFINITY, live1 ? W1 : -INFINITY));
+    if (lane == 0) vc.gain[c] = g;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Exact chain with verified jumps.  One four-wave workgroup per interval; the step is k_viterbi_wide's (wave w owns
+// the from-states [w NP / 4, (w + 1) NP / 4), partial maxima meet in LDS behind one barrier per step, every wave
+// combines them itself), the blocks are 16 positions (TEHMM_PB) and their sequence is dynamic.
+// ------------------------------------------------------------------------------------------
+template <bool RATIO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_vit_wide_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, int NP, const double *g_lt, const double *g_pi,
+                    const double *tratios, int TBW, uint8_t *tb, int *last_state, double *logprob, int *stats) {
+  extern __shared__ double sm[];
+  constexpr int W = TEHMM_WIDE_W, QM = TEHMM_WIDE_QM;
+  double *ring = sm;
+  double *vown = ring + TEHMM_PB * W;
+  double *pval = vown + 8 * W;
+  int *parg = (int *)(pval + 8 * W);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int id = iv.order[blockIdx.x];
+  const int64_t T = iv.len[id];
+  const int64_t p0 = iv.pos0[id];
+  if (T <= 0) return;
+  const int Q = NP / 4, f0 = w * Q;
+  double ltq[2][QM], ltd[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int j = lane + 64 * s;
+    ltd[s] = j < N ? g_lt[(size_t)j * NP + j] : 0.0;
+#pragma unroll
+    for (int i = 0; i < QM; ++i) {
+      const int f = f0 + i;
+      ltq[s][i] = (i < Q && f < N && j < N) ? g_lt[(size_t)f * NP + j] : -INFINITY;
+    }
+  }
+  const double lt00 = g_lt[0];
+  double *vmine = vown + w * 2 * W;
+  vmine[lane] = vmine[lane + 64] = vmine[W + lane] = vmine[W + lane + 64] = -INFINITY;
+  const double *ltab = wide_stage_table(em, sm);
+  __syncthreads();
+  bool seen = false;
+  int64_t fg = T;
+  int cur = 0;
+  const int64_t cfirst = vc.first[id];
+  const int CS = vc.CS;
+  int n_block = 0, n_jump = 0;
+  double vfin[2] = {-INFINITY, -INFINITY};          // this lane's two states of the current vector
+  int64_t t0 = 0, since = 0;                        // block start; where the exact run (re)started
+  while (t0 < T) {
+    ++n_block;
+    const int np = (int)min((int64_t)TEHMM_PB, T - t0);
+    wide_emission_block<0, false>(em, p0 + t0, t0, np, lane, w, N, ltd, nullptr, seen, fg, ring, nullptr, ltab);
+    __syncthreads();
+    // chunk of this block and whether it can be verified against the quantised pass: check row g = first recorded
+    // row at least TEHMM_FIX_MINSTEP steps into the block; landing position = next tie behind g or the chunk end
+    const int64_t c = cfirst + t0 / CS;
+    const int64_t ct0 = vc.t0[c];
+    const int e = vc.e[c];
+    const bool spec = e != TEHMM_SPEC_NONE && np == TEHMM_PB && vc.ok[c] != 0 && seen;
+    // a block of 16 positions holds exactly one recorded row (positions = 15 mod 16 of the chunk): the chain checks
+    // there once it has run TEHMM_FIX_MINSTEP exact steps since it (re)started (rank convergence takes 3-16 steps;
+    // a check that comes too early simply fails and the next block tries again)
+    const int64_t g = t0 + (TEHMM_VROW - 1 - ((t0 - ct0) & (TEHMM_VROW - 1)));
+    const bool check_here = spec && g < t0 + np && g < ct0 + CS && g >= since + TEHMM_FIX_MINSTEP;
+    int64_t target = ct0 + CS;
+    const double *trow = vc.rows + ((c * (CS / TEHMM_VROW)) + (CS / TEHMM_VROW - 1)) * NP;
+    if (check_here) {
+      // landing position: the first rounding tie behind g (the row before it was recorded) or the chunk end
+      const int ntie = vc.ntie[c];
+      const int *tl = vc.ties + c * TEHMM_SPEC_MAXT;
+      for (int k = 0; k < ntie; ++k) {
+        const int64_t tp = ct0 + tl[k];
+        if (tp > g) { target = tp; trow = vc.tierows + (c * TEHMM_SPEC_MAXT + k) * NP; break; }
+      }
+    }
+    const bool do_check = check_here && target >= t0 + np;
+    const int pg = (int)(g - t0);
+    double wrow[2] = {0.0, 0.0}, wend[2] = {0.0, 0.0};
+    double span = 0.0;
+    if (do_check) {
+      const double *rr = vc.rows + ((c * (CS / TEHMM_VROW)) + (g - ct0) / TEHMM_VROW) * NP;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int j = lane + 64 * s;
+        wrow[s] = j < N ? rr[j] : -INFINITY;
+        wend[s] = j < N ? trow[j] : -INFINITY;
+      }
+      span = fabs(vc.gain[c]) * 1.01 + 256.0;
+    }
+    bool jumped = false;
+    for (int p = 0; p < np; ++p) {
+      const int64_t t = t0 + p;
+      const double b[2] = {ring[p * W + lane], ring[p * W + lane + 64]};
+      double r = 0.0;
+      if (RATIO) r = tratios[p0 + t];
+      const double *vp = vmine + cur * W;
+      double *vn = vmine + (cur ^ 1) * W;
+      if (t == 0) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int j = lane + 64 * s;
+          double v = (j < N ? g_pi[j] : -INFINITY) + b[s];
+          if (RATIO && r > 1.) v += ltd[s] * (r - 1.);
+          vfin[s] = j < N ? v : -INFINITY;
+          vn[j] = vfin[s];
+        }
+      } else {
+        const bool rg = RATIO && r > 1.;
+        const double rm1 = r - 1.;
+        double best[2] = {-INFINITY, -INFINITY};
+        int arg[2] = {0, 0};
+        if (w == 0) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            double cc = (vp[0] + ltq[s][0]) + b[s];
+            if (RATIO) {
+              cc += ltd[s] * r;
+              if (lane + 64 * s == 0) cc -= lt00;
+            }
+            best[s] = cc;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < QM; ++i) {
+          if (i == 0 && w == 0) continue;                    // (uniform per wave)
+          const double vf = vp[min(f0 + i, W - 1)];
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            double cc = (vf + ltq[s][i]) + b[s];
+            if (rg) cc += ltd[s] * rm1;
+            if (cc > best[s]) { best[s] = cc; arg[s] = f0 + i; }
+          }
+        }
+        const int par = (int)(t & 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          pval[(par * 4 + w) * W + lane + 64 * s] = best[s];
+          parg[(par * 4 + w) * W + lane + 64 * s] = arg[s];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int j = lane + 64 * s;
+          double fin = pval[(par * 4 + 0) * W + j];
+          int fa = parg[(par * 4 + 0) * W + j];
+#pragma unroll
+          for (int ww = 1; ww < 4; ++ww) {
+            const double cc = pval[(par * 4 + ww) * W + j];
+            if (cc > fin) { fin = cc; fa = parg[(par * 4 + ww) * W + j]; }
+          }
+          vfin[s] = j < N ? fin : -INFINITY;
+          vn[j] = vfin[s];
+          if (w == 0 && j < N) tb[(p0 + t) * TBW + j] = (uint8_t)fa;
+        }
+      }
+      cur ^= 1;
+      if (do_check && p == pg) {
+        // verified iff V - W is one constant over the live states, every V is in the binade the chunk was
+        // quantised for, and (by the chunk's P0 gain) stays in it up to the landing position.  Every wave holds
+        // the whole vector: all four take the same decision.
+        double d[2], dmx = -INFINITY, vmn = INFINITY;
+        bool okl = true;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int j = lane + 64 * s;
+          const bool lv = j < N;
+          const bool both_dead = vfin[s] == -INFINITY && wrow[s] == -INFINITY;
+          d[s] = vfin[s] - wrow[s];
+          if (lv && !both_dead) {
+            dmx = fmax(dmx, d[s]);
+            vmn = fmin(vmn, vfin[s]);
+            okl = okl && exp_of(-vfin[s]) == e + 1;           // 2^e <= |v| < 2^(e+1)
+          }
+        }
+        const double d0 = wave_max_f64(dmx);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int j = lane + 64 * s;
+          const bool both_dead = vfin[s] == -INFINITY && wrow[s] == -INFINITY;
+          if (j < N && !both_dead) okl = okl && d[s] == d0;
+        }
+        const double vlow = wave_min_f64(vmn) - span;
+        const bool endok = d0 == d0 && d0 > -INFINITY && vlow > -INFINITY && exp_of(-vlow) == e + 1;
+        if (__all(okl) && endok) {
+          // V at position target - 1 (exact: both multiples of u inside one binade)
+          double *vj = vmine + cur * W;
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const int j = lane + 64 * s;
+            vfin[s] = j < N ? wend[s] + d0 : -INFINITY;
+            vj[j] = vfin[s];
+          }
+          jumped = true;
+          t0 = target;
+          since = target;
+          ++n_jump;
+          break;
+        }
+      }
+    }
+    if (!jumped) t0 += np;
+    __syncthreads();
+  }
+  // np.argmax over V[T-1] (first maximum; a NaN wins as soon as it is met)
+  if (threadIdx.x == 0) {
+    const double *v = vmine + cur * W;
+    int last = 0;
+    double m = v[0];
+    if (m == m) {
+      for (int j = 1; j < N; ++j) {
+        const double x = v[j];
+        if (x != x) { last = j; break; }
+        if (x > m) { m = x; last = j; }
+      }
+    }
+    last_state[id] = last;
+    logprob[id] = v[last];
+    if (stats) { atomicAdd(&stats[0], n_block); atomicAdd(&stats[1], n_jump); }
+  }
+}
+
 }  // namespace tehmm
