@@ -207,6 +207,10 @@ struct WideWork {
   DBuf<float> AL;
   // chunk-parallel exact Viterbi (k_vit_wide_spec / k_vit_wide_fix)
   DBuf<double> BL;                 // log emission rows [internal position][128]
+  DBuf<double> rows2;              // recorded rows of the second tie hypothesis
+  DBuf<uint8_t> tb2;               // its traceback bytes
+  DBuf<int64_t> sel_from;          // per chunk: first position the chain adopted from the quantised pass
+  DBuf<int> sel_hyp;               // per chunk: which hypothesis it adopted (-1: none)
   DBuf<int> wk_c, wk_e;            // work lists: 8 chunks of one binade per workgroup
   std::vector<int> h_wkc, h_wke, h_e;
   std::vector<double> h_gain;
@@ -1640,6 +1644,10 @@ static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalT
   const int nc = sw.n_chunks;
   if (nc <= 0) return TEHMM_OK;
   HIPCHK(w.BL.ensure((size_t)b->total_pad * TEHMM_WIDE_S + TEHMM_WIDE_S));
+  HIPCHK(w.rows2.ensure((size_t)nc * (CS / TEHMM_VROW) * m->NP + 1));
+  HIPCHK(w.tb2.ensure((size_t)(b->total_pad + 1) * b->TBW));
+  HIPCHK(w.sel_from.ensure((size_t)nc + 1));
+  HIPCHK(w.sel_hyp.ensure((size_t)nc + 1));
   VitChunks vc;
   std::memset(&vc, 0, sizeof(vc));
   vc.iv = sw.iv.p; vc.t0 = sw.t0.p; vc.first = sw.first.p; vc.n = nc; vc.CS = CS;
@@ -1647,7 +1655,7 @@ static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalT
   vc.ntie = sw.ntie.p; vc.ties = sw.ties.p; vc.tierows = sw.tierows.p; vc.segmin = sw.segmin.p;
   const EmisTab emg = without_lds_tables(em);
   hipLaunchKernelGGL(k_wide_logrows, dim3((nc + 3) / 4), dim3(256), 0, st, iv, emg, vc, m->N, w.BL.p);
-  const size_t lds = (size_t)m->N * TEHMM_WIDE_S * sizeof(double) + 64;
+  const size_t lds = (size_t)m->N * TEHMM_WIDE_S * sizeof(double) + 64 + TEHMM_WIDE_MAXTT * sizeof(int);
   // P0: plain gains of every chunk
   {
     const int nwg = (nc + 7) / 8;
@@ -1661,12 +1669,12 @@ static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalT
       allow_lds(k_vit_wide_spec<false, true>, lds);
       hipLaunchKernelGGL((k_vit_wide_spec<false, true>), dim3(nwg), dim3(512), lds, st, iv, vc, m->N, m->NP,
                          (const double *)m->lt.p, (const double *)w.BL.p, (const double *)b->ratios.p,
-                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, b->tb.p);
+                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, b->tb.p, w.tb2.p, w.rows2.p);
     } else {
       allow_lds(k_vit_wide_spec<false, false>, lds);
       hipLaunchKernelGGL((k_vit_wide_spec<false, false>), dim3(nwg), dim3(512), lds, st, iv, vc, m->N, m->NP,
                          (const double *)m->lt.p, (const double *)w.BL.p, (const double *)nullptr,
-                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, b->tb.p);
+                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, b->tb.p, w.tb2.p, w.rows2.p);
     }
     w.h_gain.resize((size_t)nc);
     HIPCHK(hipMemcpyAsync(w.h_gain.data(), sw.gain.p, (size_t)nc * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1674,8 +1682,6 @@ static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalT
   }
   // binades; work lists of P2: the speculated chunks sorted by binade, eight to a workgroup
   spec_assign_binades(b, w.h_gain, w.h_e);
-  for (int c = 0; c < nc; ++c)        // seven index bits: a state may fall 2^(e - 7) behind inside a re-basing window
-    if (w.h_e[(size_t)c] != TEHMM_SPEC_NONE && w.h_e[(size_t)c] < TEHMM_SPEC_MIN_E + 1) w.h_e[(size_t)c] = TEHMM_SPEC_NONE;
   std::vector<int> order;
   for (int c = 0; c < nc; ++c)
     if (w.h_e[(size_t)c] != TEHMM_SPEC_NONE) order.push_back(c);
@@ -1694,6 +1700,7 @@ static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalT
   HIPCHK(hipMemsetAsync(sw.ok.p, 0, (size_t)nc * sizeof(int), st));
   HIPCHK(hipMemsetAsync(sw.ntie.p, 0, (size_t)nc * sizeof(int), st));
   HIPCHK(hipMemsetAsync(sw.stats.p, 0, 2 * sizeof(int), st));
+  HIPCHK(hipMemsetAsync(w.sel_hyp.p, 0xff, ((size_t)nc + 1) * sizeof(int), st));
   if (nwg2 > 0) {
     HIPCHK(w.wk_c.ensure(w.h_wkc.size() + 8));
     HIPCHK(w.wk_e.ensure(w.h_wke.size() + 8));
@@ -1703,12 +1710,12 @@ static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalT
       allow_lds(k_vit_wide_spec<true, true>, lds);
       hipLaunchKernelGGL((k_vit_wide_spec<true, true>), dim3(nwg2), dim3(512), lds, st, iv, vc, m->N, m->NP,
                          (const double *)m->lt.p, (const double *)w.BL.p, (const double *)b->ratios.p,
-                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, b->tb.p);
+                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, b->tb.p, w.tb2.p, w.rows2.p);
     } else {
       allow_lds(k_vit_wide_spec<true, false>, lds);
       hipLaunchKernelGGL((k_vit_wide_spec<true, false>), dim3(nwg2), dim3(512), lds, st, iv, vc, m->N, m->NP,
                          (const double *)m->lt.p, (const double *)w.BL.p, (const double *)nullptr,
-                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, b->tb.p);
+                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, b->tb.p, w.tb2.p, w.rows2.p);
     }
   }
   // the exact chain
@@ -1717,12 +1724,39 @@ static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalT
     allow_lds(k_vit_wide_fix<true>, ldsf);
     hipLaunchKernelGGL((k_vit_wide_fix<true>), dim3(b->n), dim3(256), ldsf, st, iv, em, vc, m->N, m->NP, (const double *)m->lt.p,
                        (const double *)m->pi.p, (const double *)b->ratios.p, b->TBW, b->tb.p, b->last_state.p, b->vit_lp.p,
-                       sw.stats.p);
+                       sw.stats.p, (const double *)w.rows2.p, (const double *)w.BL.p, w.sel_from.p, w.sel_hyp.p);
   } else {
     allow_lds(k_vit_wide_fix<false>, ldsf);
     hipLaunchKernelGGL((k_vit_wide_fix<false>), dim3(b->n), dim3(256), ldsf, st, iv, em, vc, m->N, m->NP, (const double *)m->lt.p,
                        (const double *)m->pi.p, (const double *)nullptr, b->TBW, b->tb.p, b->last_state.p, b->vit_lp.p,
-                       sw.stats.p);
+                       sw.stats.p, (const double *)w.rows2.p, (const double *)w.BL.p, w.sel_from.p, w.sel_hyp.p);
+  }
+  hipLaunchKernelGGL(k_wide_tb_select, dim3(nc), dim3(256), 0, st, iv, vc, m->N, b->TBW, b->tb.p, (const uint8_t *)w.tb2.p,
+                     (const int64_t *)w.sel_from.p, (const int *)w.sel_hyp.p);
+  if (std::getenv("TEHMM_SPEC_DEBUG")) {
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<int> hok((size_t)nc), hnt((size_t)nc), hsel((size_t)nc);
+    HIPCHK(hipMemcpy(hok.data(), sw.ok.p, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hnt.data(), sw.ntie.p, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hsel.data(), w.sel_hyp.p, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost));
+    int n_spec = 0, n_ok = 0, n_sel[3] = {0, 0, 0};
+    long ties = 0;
+    for (int c = 0; c < nc; ++c) {
+      if (w.h_e[(size_t)c] == TEHMM_SPEC_NONE) continue;
+      ++n_spec;
+      n_ok += hok[(size_t)c] != 0;
+      ties += hnt[(size_t)c];
+      ++n_sel[hsel[(size_t)c] < 0 ? 2 : hsel[(size_t)c]];
+    }
+    std::fprintf(stderr, "[tehmm wide vit] chunks %d, speculated %d, usable %d, tie positions %ld, adopted h0 %d h1 %d none %d\n", nc,
+                 n_spec, n_ok, ties, n_sel[0], n_sel[1], n_sel[2]);
+    for (int e = 10; e < 30; ++e) {
+      int ne = 0, nok = 0, nsel = 0;
+      long nt = 0;
+      for (int c = 0; c < nc; ++c)
+        if (w.h_e[(size_t)c] == e) { ++ne; nok += hok[(size_t)c] != 0; nsel += hsel[(size_t)c] >= 0; nt += hnt[(size_t)c]; }
+      if (ne) std::fprintf(stderr, "  binade %d: chunks %d usable %d adopted %d tie positions %ld\n", e, ne, nok, nsel, nt);
+    }
   }
   *done = true;
   return TEHMM_OK;

@@ -22,6 +22,7 @@
 // Tolerance: posteriors to 1e-6 (alpha' rows are kept as floats between the passes, as in the fused passes);
 // the forward log-likelihood is summed in fp64 from the items' scale records and the links' ratios.
 #pragma once
+#include <type_traits>
 #include "tehmm_fused.hip.h"
 
 namespace tehmm {
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(64) void k_wide_loglik(IntervalTab iv, LaneGeom lg,
 // tehmm_spec.hip.h; the chain lands exactly on them.
 // ==========================================================================================================
 #define TEHMM_WIDE_S 128            // row stride of the wide log-row buffer and of the LDS table
+#define TEHMM_WIDE_MAXTT 8          // transition-table entries per binade that may be rounding ties
 
 __device__ __forceinline__ double wide_readlane(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
@@ -345,11 +347,24 @@ __global__ __launch_bounds__(256) void k_wide_logrows(IntervalTab iv, EmisTab em
 
 // block = 512: eight chunks of one binade (wk_c [8 per workgroup], -1 = none; wk_e [workgroup]); QUANT = false:
 // plain fp64 gains of every listed chunk (P0).  LDS: table [N][128] | flag
+//
+// Rounding ties.  Where an addend of the reference's sum (b, lt[j][j] r, lt[j][j] (r - 1)) lies exactly between two
+// grid points, fl(v + z) depends on the PARITY of v / u -- candidate by candidate, because the reference adds b and
+// the ratio term inside the max (_hmm.pyx:232-244).  At 100 states and with segment ratios such positions are
+// frequent (a tie is a property of the VALUE: one in ~2^(e-5) per state and position for b, and the few hundred
+// distinct products lt[j][j] r recur all along the data), so ending a segment at each of them -- as the narrow
+// kernels do -- leaves the chain walking most of a chunk.  Instead the pass carries BOTH hypotheses about the
+// constant delta between its frame and the true values, delta / u even (h = 0) and odd (h = 1): under a hypothesis
+// the parity of a true value is known from the speculative one, every candidate's sum is rounded half-to-even on
+// its own parity, and the recurrence stays exact THROUGH the tie.  Two vectors, two sets of recorded rows and of
+// traceback bytes (the second set written from the chunk's first tie on: before it the hypotheses agree); the chain
+// learns delta when it verifies the chunk and adopts the set whose parity matches.
 template <bool QUANT, bool RATIO>
 __global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks vc, int N, int NP,
                                                        const double *__restrict__ g_lt, const double *__restrict__ BL,
                                                        const double *__restrict__ tratios, const int *__restrict__ wk_c,
-                                                       const int *__restrict__ wk_e, int TBW, uint8_t *tb) {
+                                                       const int *__restrict__ wk_e, int TBW, uint8_t *tb, uint8_t *tb2,
+                                                       double *rows2) {
   extern __shared__ double wsm[];
   double *tq = wsm;
   volatile int *tflag = (volatile int *)(wsm + (size_t)N * TEHMM_WIDE_S);
@@ -360,20 +375,34 @@ __global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks
   const double CM = QUANT ? ldexp(1.0, e + 1) - ldexp(1.0, e - 44) : 0.0;          // 2^(e+1) - 256 u
   const double wlim = QUANT ? -(ldexp(1.0, e) - ldexp(1.5, e - 44)) : -INFINITY;   // -(2^e - 384 u)
   const double zlim = QUANT ? ldexp(1.0, e - 1) : INFINITY;
-  if (threadIdx.x == 0) *tflag = 0;
+  const double i2u = QUANT ? ldexp(1.0, 51 - e) : 0.0;                             // 1 / (2 u)
+  // LDS behind the table: flag | number of tie entries | tie entries (from | to << 8 | parity of the lower neighbour << 16)
+  volatile int *ntt = tflag + 1;
+  volatile int *ttab = tflag + 2;
+  if (threadIdx.x == 0) { *tflag = 0; *ntt = 0; }
   __syncthreads();
   for (int i = threadIdx.x; i < N * TEHMM_WIDE_S; i += blockDim.x) {
     const int f = i >> 7, j = i & 127;
     const double z = j < N ? g_lt[(size_t)f * NP + j] : -INFINITY;
     double val = z;
     if (QUANT) {
-      const double q = (z + M) - M;
-      if (z > -INFINITY && (fabs(z - q) == half_u || !(fabs(z) < zlim))) *tflag = 1;   // exact tie / out of range
+      double q = (z + M) - M;
+      if (z > -INFINITY && !(fabs(z) < zlim)) *tflag = 1;       // out of the range of the rounding trick
+      if (z > -INFINITY && fabs(z - q) == half_u) {
+        // a transition exactly between two grid points: fl(V[f] + z) depends on the parity of V[f] / u.  The table
+        // holds the LOWER neighbour; the step adds u where round-half-even goes up (k_vit_wide_spec, tie_adj)
+        const double qo = 2.0 * z - q;                          // the odd neighbour (q / u is even)
+        const int k = atomicAdd((int *)ntt, 1);
+        if (k < TEHMM_WIDE_MAXTT) ttab[k] = f | (j << 8) | ((qo < q ? 1 : 0) << 16);
+        else *tflag = 1;
+        q = fmin(q, qo);
+      }
       val = 128.0 * q + (double)(127 - f) * u;                  // -inf stays -inf
     }
     tq[i] = val;
   }
   __syncthreads();
+  const int n_tt = QUANT ? min((int)*ntt, TEHMM_WIDE_MAXTT) : 0;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = wk_c[blockIdx.x * 8 + w];
   if (c < 0) return;
@@ -382,9 +411,20 @@ __global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks
   const int CS = vc.CS;
   const int len = (int)min((int64_t)CS, iv.len[id] - t0);     // (P0 also runs ragged tails; P2 only full chunks)
   const bool live0 = lane < N, live1 = lane + 64 < N;
-  double W0 = live0 ? 0.0 : -INFINITY, W1 = live1 ? 0.0 : -INFINITY;      // QUANT: 128 x (value - base)
-  double base = 0.0;
-  int nt = 0;
+  constexpr int H = QUANT ? 2 : 1;
+  double W0[H], W1[H], base[H];          // QUANT: 128 x (value - base) of the lane's two states, per hypothesis
+  int pb[H];                             // parity of base / u, XOR the hypothesis
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    W0[h] = live0 ? 0.0 : -INFINITY;
+    W1[h] = live1 ? 0.0 : -INFINITY;
+    base[h] = 0.0;
+    pb[h] = h;
+  }
+  // a tie has been met: the two hypotheses are computed separately from here (from the start when the binade's
+  // transition table itself has tie entries: their rounding follows the hypothesis at every step)
+  int nt = 0, first_tie = n_tt > 0 ? 0 : CS;
+  bool diverged = n_tt > 0;
   bool bad = QUANT && *tflag != 0;
   const double ltd0 = live0 ? g_lt[(size_t)lane * NP + lane] : 0.0;
   const double ltd1 = live1 ? g_lt[(size_t)(lane + 64) * NP + lane + 64] : 0.0;
@@ -393,6 +433,7 @@ __global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks
   if (QUANT && RATIO && (fabs(lt00 - lt00q) == half_u || !(fabs(lt00) < zlim))) bad = true;
   const double *bp = BL + (p0 + t0) * TEHMM_WIDE_S;
   double bn0 = bp[lane], bn1 = bp[lane + 64];
+  const int n0 = min(N, 64);
   for (int s = 0; s < len; ++s) {
     const int64_t t = t0 + s;
     const double b0 = bn0, b1 = bn1;
@@ -401,19 +442,22 @@ __global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks
       bn1 = bp[(int64_t)(s + 1) * TEHMM_WIDE_S + lane + 64];
     }
     // ---- segment-ratio terms of this position
-    bool tie = false;
     double add0 = 0.0, add1 = 0.0;       // what every candidate from >= 1 gets (QUANT: grid-rounded, not yet x 128)
     double dz0 = 0.0, dz1 = 0.0;         // what candidate 0 gets on top of that
+    double za0 = 0.0, za1 = 0.0, zb0 = 0.0, zb1 = 0.0, qa0 = 0.0, qa1 = 0.0, qb0 = 0.0, qb1 = 0.0;
+    bool tza0 = false, tza1 = false, tzb0 = false, tzb1 = false, rg = false;
     if (RATIO) {
       const double r = tratios[p0 + t];
-      const bool rg = r > 1.0;
-      const double za0 = ltd0 * r, za1 = ltd1 * r;                         // from == 0: lt[j][j] * r, always
-      const double zb0 = ltd0 * (r - 1.0), zb1 = ltd1 * (r - 1.0);         // from >= 1: lt[j][j] * (r - 1) if r > 1
+      rg = r > 1.0;
+      za0 = ltd0 * r; za1 = ltd1 * r;                          // from == 0: lt[j][j] * r, always
+      zb0 = ltd0 * (r - 1.0); zb1 = ltd1 * (r - 1.0);          // from >= 1: lt[j][j] * (r - 1) if r > 1
       if (QUANT) {
-        const double qa0 = (za0 + M) - M, qa1 = (za1 + M) - M;
-        const double qb0 = rg ? (zb0 + M) - M : 0.0, qb1 = rg ? (zb1 + M) - M : 0.0;
-        tie = tie || (live0 && (fabs(za0 - qa0) == half_u || (rg && fabs(zb0 - qb0) == half_u)));
-        tie = tie || (live1 && (fabs(za1 - qa1) == half_u || (rg && fabs(zb1 - qb1) == half_u)));
+        qa0 = (za0 + M) - M; qa1 = (za1 + M) - M;
+        qb0 = rg ? (zb0 + M) - M : 0.0; qb1 = rg ? (zb1 + M) - M : 0.0;
+        tza0 = live0 && fabs(za0 - qa0) == half_u;
+        tza1 = live1 && fabs(za1 - qa1) == half_u;
+        tzb0 = live0 && rg && fabs(zb0 - qb0) == half_u;
+        tzb1 = live1 && rg && fabs(zb1 - qb1) == half_u;
         bad = bad || (live0 && !(fabs(za0) < zlim)) || (live1 && !(fabs(za1) < zlim));
         add0 = qb0; add1 = qb1;
         dz0 = (qa0 - qb0) - (lane == 0 ? lt00q : 0.0);
@@ -424,85 +468,189 @@ __global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks
         dz1 = za1 - add1;
       }
     }
-    // ---- x[j] = max_f W[f] + table[f][j]  (QUANT: the table carries 127 - f in its low bits: the first arg-max wins)
-    const double s0 = wide_readlane(W0, 0);
-    double x0 = s0 + tq[lane], x1 = s0 + tq[lane + 64];
-    if (RATIO) {
-      x0 += QUANT ? 128.0 * dz0 : dz0;
-      x1 += QUANT ? 128.0 * dz1 : dz1;
-    }
-    const int n0 = min(N, 64);
-#pragma unroll 4
-    for (int f = 1; f < n0; ++f) {
-      const double sv = wide_readlane(W0, f);
-      x0 = fmax(x0, sv + tq[f * TEHMM_WIDE_S + lane]);
-      x1 = fmax(x1, sv + tq[f * TEHMM_WIDE_S + lane + 64]);
-    }
-#pragma unroll 4
-    for (int f = 64; f < N; ++f) {
-      const double sv = wide_readlane(W1, f - 64);
-      x0 = fmax(x0, sv + tq[f * TEHMM_WIDE_S + lane]);
-      x1 = fmax(x1, sv + tq[f * TEHMM_WIDE_S + lane + 64]);
-    }
-    if (QUANT) {
-      const double bq0 = (b0 + M) - M, bq1 = (b1 + M) - M;
-      tie = tie || (live0 && fabs(b0 - bq0) == half_u) || (live1 && fabs(b1 - bq1) == half_u);
-      bad = bad | (b0 != b0);
-      if (__any(tie)) {
-        // a rounding tie at this position: close the segment (record W_{t-1}), restart from zeros; the exact chain
-        // handles position t itself
-        if (nt < TEHMM_SPEC_MAXT) {
-          if (lane == 0) vc.ties[(int64_t)c * TEHMM_SPEC_MAXT + nt] = (int)(t - t0);
-          double *tr = vc.tierows + ((int64_t)c * TEHMM_SPEC_MAXT + nt) * NP;
-          tr[lane] = live0 ? W0 * 0.0078125 + base : -INFINITY;
-          if (lane + 64 < NP) tr[lane + 64] = live1 ? W1 * 0.0078125 + base : -INFINITY;
-        }
-        ++nt;
-        W0 = live0 ? 0.0 : -INFINITY;
-        W1 = live1 ? 0.0 : -INFINITY;
-        base = 0.0;
-      } else {
-        // x = 128 (best value) + (127 - first arg-max) u, exact;  x + CM has exponent e, its low seven mantissa bits
-        // are x / u mod 128
-        const double y0 = x0 + CM, y1 = x1 + CM;
-        const unsigned l0 = (unsigned)__double2loint(y0), l1 = (unsigned)__double2loint(y1);
-        const double m0 = __hiloint2double(__double2hiint(y0), (int)(l0 & ~127u)) - CM;
-        const double m1 = __hiloint2double(__double2hiint(y1), (int)(l1 & ~127u)) - CM;
-        W0 = x0 > -INFINITY ? m0 + 128.0 * (bq0 + add0) : -INFINITY;
-        W1 = x1 > -INFINITY ? m1 + 128.0 * (bq1 + add1) : -INFINITY;
-        if (live0) tb[(p0 + t) * TBW + lane] = x0 > -INFINITY ? (uint8_t)(~l0 & 127u) : (uint8_t)0;
-        if (live1) tb[(p0 + t) * TBW + lane + 64] = x1 > -INFINITY ? (uint8_t)(~l1 & 127u) : (uint8_t)0;
-        // W must stay inside the range of the arg-max extraction
-        bad = bad | (live0 && W0 <= wlim && W0 > -INFINITY) | (live1 && W1 <= wlim && W1 > -INFINITY);
+    const double bq0 = QUANT ? (b0 + M) - M : 0.0, bq1 = QUANT ? (b1 + M) - M : 0.0;
+    const bool tb0 = QUANT && live0 && fabs(b0 - bq0) == half_u, tb1 = QUANT && live1 && fabs(b1 - bq1) == half_u;
+    const bool anytie = QUANT && __any(tb0 || tb1 || tza0 || tza1 || tzb0 || tzb1);
+    if (QUANT) bad = bad | (b0 != b0);
+    // ---- transitions that are rounding ties in this binade (rare: a handful per binade at most): the table holds
+    // the lower neighbour of fl(V[f] + lt); round-half-even takes the upper one when the lower one is odd, i.e. when
+    // parity(V[f] / u) differs from the parity of the entry's lower neighbour.  +128 u for that (from, to), else 0.
+    auto tie_adj = [&](auto hc, int k, double &a0, double &a1) {
+      constexpr int h = decltype(hc)::value;
+      const int ent = ttab[k];
+      const int f = ent & 255, j = (ent >> 8) & 255, pz = (ent >> 16) & 1;
+      const double wf = f < 64 ? wide_readlane(W0[h], f) : wide_readlane(W1[h], f - 64);
+      // V[f] = W[f] / 128 + base: W[f] is a multiple of 128 u, its parity bit is bit 7 of W[f] / u
+      const int pv = (int)(((unsigned)__double2loint(wf + CM) >> 7) & 1u) ^ pb[h];
+      const bool up = wf > -INFINITY && (pv ^ pz) != 0;
+      a0 = (up && j == lane) ? 128.0 * u : 0.0;
+      a1 = (up && j == lane + 64) ? 128.0 * u : 0.0;
+      return f;
+    };
+    // ---- one hypothesis, no tie at this position: x[j] = max_f W[f] + table[f][j] (the table carries 127 - f in its
+    // low bits: the first arg-max wins), then the grid-rounded addends
+    auto fast = [&](auto hc) {
+      constexpr int h = decltype(hc)::value;
+      const double s0 = wide_readlane(W0[h], 0);
+      double x0 = s0 + tq[lane], x1 = s0 + tq[lane + 64];
+      if (RATIO) {
+        x0 += QUANT ? 128.0 * dz0 : dz0;
+        x1 += QUANT ? 128.0 * dz1 : dz1;
       }
-      if ((s & (TEHMM_VROW - 1)) == TEHMM_VROW - 1) {
-        if ((s & 31) == 31) {
-          const double mx = wave_max_f64(fmax(live0 ? W0 : -INFINITY, live1 ? W1 : -INFINITY));
-          if (mx > -INFINITY) {
-            W0 -= mx;
-            W1 -= mx;
-            base += mx * 0.0078125;
+#pragma unroll 4
+      for (int f = 1; f < n0; ++f) {
+        const double sv = wide_readlane(W0[h], f);
+        x0 = fmax(x0, sv + tq[f * TEHMM_WIDE_S + lane]);
+        x1 = fmax(x1, sv + tq[f * TEHMM_WIDE_S + lane + 64]);
+      }
+#pragma unroll 4
+      for (int f = 64; f < N; ++f) {
+        const double sv = wide_readlane(W1[h], f - 64);
+        x0 = fmax(x0, sv + tq[f * TEHMM_WIDE_S + lane]);
+        x1 = fmax(x1, sv + tq[f * TEHMM_WIDE_S + lane + 64]);
+      }
+      if (QUANT) {
+        for (int k = 0; k < n_tt; ++k) {      // (the loop above already holds these candidates at the lower neighbour)
+          double a0, a1;
+          const int f = tie_adj(hc, k, a0, a1);
+          const double sv = f < 64 ? wide_readlane(W0[h], f) : wide_readlane(W1[h], f - 64);
+          double c0 = sv + tq[f * TEHMM_WIDE_S + lane] + a0, c1 = sv + tq[f * TEHMM_WIDE_S + lane + 64] + a1;
+          if (RATIO && f == 0) {
+            c0 += 128.0 * dz0;
+            c1 += 128.0 * dz1;
+          }
+          x0 = fmax(x0, c0);
+          x1 = fmax(x1, c1);
+        }
+        W0[h] = x0 + 128.0 * (bq0 + add0);    // (multiples of 128 u: the index bits ride along)
+        W1[h] = x1 + 128.0 * (bq1 + add1);
+      } else {
+        W0[h] = (x0 + b0) + add0;
+        W1[h] = (x1 + b1) + add1;
+      }
+    };
+    // ---- one hypothesis at a tie position: every candidate rounded half-to-even on its own parity
+    auto slow = [&](auto hc) {
+      constexpr int h = decltype(hc)::value;
+      const int pbq0 = __builtin_amdgcn_fract(bq0 * i2u) != 0.0, pbq1 = __builtin_amdgcn_fract(bq1 * i2u) != 0.0;
+      const double bo0 = 2.0 * b0 - bq0, bo1 = 2.0 * b1 - bq1;         // the other neighbour of a tied addend
+      const double qao0 = 2.0 * za0 - qa0, qao1 = 2.0 * za1 - qa1, qbo0 = 2.0 * zb0 - qb0, qbo1 = 2.0 * zb1 - qb1;
+      const int ph = pb[h];
+      double x0 = -INFINITY, x1 = -INFINITY;
+      auto cand = [&](double sv, int f) {
+        double c0 = sv + tq[f * TEHMM_WIDE_S + lane], c1 = sv + tq[f * TEHMM_WIDE_S + lane + 64];
+        for (int k = 0; k < n_tt; ++k)
+          if ((ttab[k] & 255) == f) {
+            double a0, a1;
+            (void)tie_adj(hc, k, a0, a1);
+            c0 += a0;
+            c1 += a1;
+          }
+        // parity of (V[f] + lt) / u: bit 7 of the candidate's integer (its low seven bits are the index)
+        const int p0a = (int)(((unsigned)__double2loint(c0 + CM) >> 7) & 1u) ^ ph;
+        const int p1a = (int)(((unsigned)__double2loint(c1 + CM) >> 7) & 1u) ^ ph;
+        const double be0 = (tb0 && p0a) ? bo0 : bq0, be1 = (tb1 && p1a) ? bo1 : bq1;
+        const int p0b = tb0 ? 0 : (p0a ^ pbq0), p1b = tb1 ? 0 : (p1a ^ pbq1);     // a tied sum comes out even
+        double z0 = 0.0, z1 = 0.0;
+        if (RATIO) {
+          if (f == 0) {
+            z0 = ((tza0 && p0b) ? qao0 : qa0) - (lane == 0 ? lt00q : 0.0);
+            z1 = (tza1 && p1b) ? qao1 : qa1;
           } else {
-            bad = true;                                   // the whole vector died
+            z0 = rg ? ((tzb0 && p0b) ? qbo0 : qb0) : 0.0;
+            z1 = rg ? ((tzb1 && p1b) ? qbo1 : qb1) : 0.0;
           }
         }
-        double *row = vc.rows + ((int64_t)c * (CS / TEHMM_VROW) + s / TEHMM_VROW) * NP;
-        row[lane] = live0 ? W0 * 0.0078125 + base : -INFINITY;
-        if (lane + 64 < NP) row[lane + 64] = live1 ? W1 * 0.0078125 + base : -INFINITY;
+        x0 = fmax(x0, c0 + 128.0 * (be0 + z0));
+        x1 = fmax(x1, c1 + 128.0 * (be1 + z1));
+      };
+      for (int f = 0; f < n0; ++f) cand(wide_readlane(W0[h], f), f);
+      for (int f = 64; f < N; ++f) cand(wide_readlane(W1[h], f - 64), f);
+      W0[h] = x0;
+      W1[h] = x1;
+    };
+    // ---- index extraction, traceback bytes, range check of one hypothesis
+    auto finish = [&](auto hc, uint8_t *tbo) {
+      constexpr int h = decltype(hc)::value;
+      // W = 128 (new value - base) + (127 - first arg-max) u, exact;  W + CM has exponent e, its low seven mantissa
+      // bits are W / u mod 128
+      const double x0 = W0[h], x1 = W1[h];
+      const double y0 = x0 + CM, y1 = x1 + CM;
+      const unsigned l0 = (unsigned)__double2loint(y0), l1 = (unsigned)__double2loint(y1);
+      W0[h] = x0 > -INFINITY ? __hiloint2double(__double2hiint(y0), (int)(l0 & ~127u)) - CM : -INFINITY;
+      W1[h] = x1 > -INFINITY ? __hiloint2double(__double2hiint(y1), (int)(l1 & ~127u)) - CM : -INFINITY;
+      if (live0) tbo[(p0 + t) * TBW + lane] = x0 > -INFINITY ? (uint8_t)(~l0 & 127u) : (uint8_t)0;
+      if (live1) tbo[(p0 + t) * TBW + lane + 64] = x1 > -INFINITY ? (uint8_t)(~l1 & 127u) : (uint8_t)0;
+      bad = bad | (live0 && W0[h] <= wlim && W0[h] > -INFINITY) | (live1 && W1[h] <= wlim && W1[h] > -INFINITY);
+    };
+    // re-base (every 8 steps: at 128 x the range holds 2^(e-7) log units, a position costs ~25) and record
+    auto rebase = [&](auto hc) {
+      constexpr int h = decltype(hc)::value;
+      {
+        const double mx = wave_max_f64(fmax(live0 ? W0[h] : -INFINITY, live1 ? W1[h] : -INFINITY));
+        if (mx > -INFINITY) {
+          W0[h] -= mx;
+          W1[h] -= mx;
+          base[h] += mx * 0.0078125;
+          pb[h] ^= __builtin_amdgcn_fract(mx * ldexp(1.0, 44 - e)) != 0.0;     // parity of (mx / 128) / u
+        } else {
+          bad = true;                                   // the whole vector died
+        }
       }
+    };
+    auto record = [&](auto hc, double *rows) {
+      constexpr int h = decltype(hc)::value;
+      double *row = rows + ((int64_t)c * (CS / TEHMM_VROW) + s / TEHMM_VROW) * NP;
+      row[lane] = live0 ? W0[h] * 0.0078125 + base[h] : -INFINITY;
+      if (lane + 64 < NP) row[lane + 64] = live1 ? W1[h] * 0.0078125 + base[h] : -INFINITY;
+    };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, H - 1>;
+    if (!QUANT) {
+      fast(H0{});
+      continue;
+    }
+    if (anytie) {
+      first_tie = min(first_tie, s);
+      ++nt;
+      slow(H0{});
+      slow(H1{});
+      diverged = true;
     } else {
-      W0 = (x0 + b0) + add0;
-      W1 = (x1 + b1) + add1;
+      fast(H0{});
+      if (diverged) fast(H1{});
+    }
+    finish(H0{}, tb);
+    if (diverged) finish(H1{}, tb2);
+    if ((s & 7) == 7) {
+      rebase(H0{});
+      if (diverged) rebase(H1{});
+    }
+    if ((s & (TEHMM_VROW - 1)) == TEHMM_VROW - 1) {
+      record(H0{}, vc.rows);
+      if (diverged) record(H1{}, rows2);
+    }
+    if (!diverged) {                      // the hypotheses still agree: h = 1 is h = 0 with the other parity
+      W0[H - 1] = W0[0];
+      W1[H - 1] = W1[0];
+      base[H - 1] = base[0];
+      pb[H - 1] = pb[0] ^ 1;
+      if ((s & (TEHMM_VROW - 1)) == TEHMM_VROW - 1) {
+        double *row = rows2 + ((int64_t)c * (CS / TEHMM_VROW) + s / TEHMM_VROW) * NP;
+        row[lane] = live0 ? W0[0] * 0.0078125 + base[0] : -INFINITY;
+        if (lane + 64 < NP) row[lane + 64] = live1 ? W1[0] * 0.0078125 + base[0] : -INFINITY;
+      }
     }
   }
   if (QUANT) {
     const unsigned long long anybad = __ballot(bad);
     if (lane == 0) {
       vc.ntie[c] = nt;
-      vc.ok[c] = (anybad || nt > TEHMM_SPEC_MAXT) ? 0 : 1;
+      vc.ties[(int64_t)c * TEHMM_SPEC_MAXT] = first_tie;      // where the second set of traceback bytes starts
+      vc.ok[c] = anybad ? 0 : 1;
     }
   } else {
-    const double g = wave_max_f64(fmax(live0 ? W0 : -INFINITY, live1 ? W1 : -INFINITY));
+    const double g = wave_max_f64(fmax(live0 ? W0[0] : -INFINITY, live1 ? W1[0] : -INFINITY));
     if (lane == 0) vc.gain[c] = g;
   }
 }
@@ -510,12 +658,18 @@ __global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks
 // ------------------------------------------------------------------------------------------
 // Exact chain with verified jumps.  One four-wave workgroup per interval; the step is k_viterbi_wide's (wave w owns
 // the from-states [w NP / 4, (w + 1) NP / 4), partial maxima meet in LDS behind one barrier per step, every wave
-// combines them itself), the blocks are 16 positions (TEHMM_PB) and their sequence is dynamic.
+// combines them itself), the blocks are 16 positions (TEHMM_PB) and their sequence is dynamic.  Once the interval's
+// first emittable row is behind it (the leading-rows quirk, _emission.pyx:73-80, is the block kernel's business) the
+// chain takes its emission rows from the log-row buffer of k_wide_logrows -- recomputing them cost half of a step.
+// A verified chunk is adopted to its end with the hypothesis (see k_vit_wide_spec) whose parity matches delta:
+// sel_hyp [chunk] = that hypothesis, sel_from [chunk] = the first adopted position (k_wide_tb_select then moves the
+// second set of traceback bytes in where h = 1 was taken).
 // ------------------------------------------------------------------------------------------
 template <bool RATIO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_vit_wide_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, int NP, const double *g_lt, const double *g_pi,
-                    const double *tratios, int TBW, uint8_t *tb, int *last_state, double *logprob, int *stats) {
+                    const double *tratios, int TBW, uint8_t *tb, int *last_state, double *logprob, int *stats,
+                    const double *__restrict__ rows2, const double *__restrict__ BL, int64_t *sel_from, int *sel_hyp) {
   extern __shared__ double sm[];
   constexpr int W = TEHMM_WIDE_W, QM = TEHMM_WIDE_QM;
   double *ring = sm;
@@ -552,51 +706,63 @@ void k_vit_wide_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, int NP, con
   int n_block = 0, n_jump = 0;
   double vfin[2] = {-INFINITY, -INFINITY};          // this lane's two states of the current vector
   int64_t t0 = 0, since = 0;                        // block start; where the exact run (re)started
+  double bnx[2] = {0.0, 0.0};                       // log row of position tnx, requested a step ahead
+  int64_t tnx = -1;
   while (t0 < T) {
     ++n_block;
     const int np = (int)min((int64_t)TEHMM_PB, T - t0);
-    wide_emission_block<0, false>(em, p0 + t0, t0, np, lane, w, N, ltd, nullptr, seen, fg, ring, nullptr, ltab);
-    __syncthreads();
-    // chunk of this block and whether it can be verified against the quantised pass: check row g = first recorded
-    // row at least TEHMM_FIX_MINSTEP steps into the block; landing position = next tie behind g or the chunk end
+    const bool use_ring = !seen;                    // (uniform: every wave walks the leading rows alike)
+    if (use_ring) {
+      wide_emission_block<0, false>(em, p0 + t0, t0, np, lane, w, N, ltd, nullptr, seen, fg, ring, nullptr, ltab);
+      __syncthreads();
+    }
+    // chunk of this block and whether it can be verified against the quantised pass.  A block of 16 positions holds
+    // exactly one recorded row (positions = 15 mod 16 of the chunk): the chain checks there once it has run
+    // TEHMM_FIX_MINSTEP exact steps since it (re)started (rank convergence takes 3-16 steps; a check that comes too
+    // early simply fails and the next block tries again)
     const int64_t c = cfirst + t0 / CS;
     const int64_t ct0 = vc.t0[c];
     const int e = vc.e[c];
     const bool spec = e != TEHMM_SPEC_NONE && np == TEHMM_PB && vc.ok[c] != 0 && seen;
-    // a block of 16 positions holds exactly one recorded row (positions = 15 mod 16 of the chunk): the chain checks
-    // there once it has run TEHMM_FIX_MINSTEP exact steps since it (re)started (rank convergence takes 3-16 steps;
-    // a check that comes too early simply fails and the next block tries again)
     const int64_t g = t0 + (TEHMM_VROW - 1 - ((t0 - ct0) & (TEHMM_VROW - 1)));
-    const bool check_here = spec && g < t0 + np && g < ct0 + CS && g >= since + TEHMM_FIX_MINSTEP;
-    int64_t target = ct0 + CS;
-    const double *trow = vc.rows + ((c * (CS / TEHMM_VROW)) + (CS / TEHMM_VROW - 1)) * NP;
-    if (check_here) {
-      // landing position: the first rounding tie behind g (the row before it was recorded) or the chunk end
-      const int ntie = vc.ntie[c];
-      const int *tl = vc.ties + c * TEHMM_SPEC_MAXT;
-      for (int k = 0; k < ntie; ++k) {
-        const int64_t tp = ct0 + tl[k];
-        if (tp > g) { target = tp; trow = vc.tierows + (c * TEHMM_SPEC_MAXT + k) * NP; break; }
-      }
-    }
-    const bool do_check = check_here && target >= t0 + np;
+    const int64_t target = ct0 + CS;
+    const bool do_check = spec && g < t0 + np && g + 1 < target && g >= since + TEHMM_FIX_MINSTEP;
     const int pg = (int)(g - t0);
-    double wrow[2] = {0.0, 0.0}, wend[2] = {0.0, 0.0};
+    double wrow[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, wend[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
     double span = 0.0;
     if (do_check) {
-      const double *rr = vc.rows + ((c * (CS / TEHMM_VROW)) + (g - ct0) / TEHMM_VROW) * NP;
+      const int64_t ro = ((c * (CS / TEHMM_VROW)) + (g - ct0) / TEHMM_VROW) * NP;
+      const int64_t eo = ((c * (CS / TEHMM_VROW)) + (CS / TEHMM_VROW - 1)) * NP;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int j = lane + 64 * s;
-        wrow[s] = j < N ? rr[j] : -INFINITY;
-        wend[s] = j < N ? trow[j] : -INFINITY;
+        wrow[0][s] = j < N ? vc.rows[ro + j] : -INFINITY;
+        wrow[1][s] = j < N ? rows2[ro + j] : -INFINITY;
+        wend[0][s] = j < N ? vc.rows[eo + j] : -INFINITY;
+        wend[1][s] = j < N ? rows2[eo + j] : -INFINITY;
       }
       span = fabs(vc.gain[c]) * 1.01 + 256.0;
     }
     bool jumped = false;
     for (int p = 0; p < np; ++p) {
       const int64_t t = t0 + p;
-      const double b[2] = {ring[p * W + lane], ring[p * W + lane + 64]};
+      double b[2];
+      if (use_ring) {
+        b[0] = ring[p * W + lane];
+        b[1] = ring[p * W + lane + 64];
+      } else {
+        if (tnx != t) {
+          bnx[0] = BL[(p0 + t) * TEHMM_WIDE_S + lane];
+          bnx[1] = BL[(p0 + t) * TEHMM_WIDE_S + lane + 64];
+        }
+        b[0] = bnx[0];
+        b[1] = bnx[1];
+        if (t + 1 < T) {
+          bnx[0] = BL[(p0 + t + 1) * TEHMM_WIDE_S + lane];
+          bnx[1] = BL[(p0 + t + 1) * TEHMM_WIDE_S + lane + 64];
+          tnx = t + 1;
+        }
+      }
       double r = 0.0;
       if (RATIO) r = tratios[p0 + t];
       const double *vp = vmine + cur * W;
@@ -661,40 +827,60 @@ void k_vit_wide_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, int NP, con
       }
       cur ^= 1;
       if (do_check && p == pg) {
-        // verified iff V - W is one constant over the live states, every V is in the binade the chunk was
-        // quantised for, and (by the chunk's P0 gain) stays in it up to the landing position.  Every wave holds
-        // the whole vector: all four take the same decision.
-        double d[2], dmx = -INFINITY, vmn = INFINITY;
-        bool okl = true;
+        // verified iff V - W is one constant over the live states (for the hypothesis whose parity that constant
+        // has), every V is in the binade the chunk was quantised for, and (by the chunk's P0 gain) stays in it up
+        // to the chunk end.  Every wave holds the whole vector: all four take the same decision.
+        double vmn = INFINITY;
+        bool inb = true;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           const int j = lane + 64 * s;
-          const bool lv = j < N;
-          const bool both_dead = vfin[s] == -INFINITY && wrow[s] == -INFINITY;
-          d[s] = vfin[s] - wrow[s];
-          if (lv && !both_dead) {
-            dmx = fmax(dmx, d[s]);
+          if (j < N && vfin[s] > -INFINITY) {
             vmn = fmin(vmn, vfin[s]);
-            okl = okl && exp_of(-vfin[s]) == e + 1;           // 2^e <= |v| < 2^(e+1)
+            inb = inb && exp_of(-vfin[s]) == e + 1;            // 2^e <= |v| < 2^(e+1)
           }
         }
-        const double d0 = wave_max_f64(dmx);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int j = lane + 64 * s;
-          const bool both_dead = vfin[s] == -INFINITY && wrow[s] == -INFINITY;
-          if (j < N && !both_dead) okl = okl && d[s] == d0;
-        }
         const double vlow = wave_min_f64(vmn) - span;
-        const bool endok = d0 == d0 && d0 > -INFINITY && vlow > -INFINITY && exp_of(-vlow) == e + 1;
-        if (__all(okl) && endok) {
-          // V at position target - 1 (exact: both multiples of u inside one binade)
+        const bool common = __all(inb) && vlow > -INFINITY && exp_of(-vlow) == e + 1;
+        int take = -1;
+        double dtake = 0.0;
+        const double i2u = ldexp(1.0, 51 - e);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          double dmx = -INFINITY;
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const int j = lane + 64 * s;
+            const bool both_dead = vfin[s] == -INFINITY && wrow[h][s] == -INFINITY;
+            if (j < N && !both_dead) dmx = fmax(dmx, vfin[s] - wrow[h][s]);
+          }
+          const double d0 = wave_max_f64(dmx);
+          bool okl = true;
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const int j = lane + 64 * s;
+            const bool both_dead = vfin[s] == -INFINITY && wrow[h][s] == -INFINITY;
+            if (j < N && !both_dead) okl = okl && (vfin[s] - wrow[h][s]) == d0;
+          }
+          const bool fin = d0 == d0 && d0 > -INFINITY && d0 < INFINITY;
+          const bool odd = fin && __builtin_amdgcn_fract(d0 * i2u) != 0.0;
+          if (take < 0 && fin && __all(okl) && (int)odd == h) {
+            take = h;
+            dtake = d0;
+          }
+        }
+        if (common && take >= 0) {
+          // V at the chunk's last position (exact: both multiples of u inside one binade)
           double *vj = vmine + cur * W;
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
             const int j = lane + 64 * s;
-            vfin[s] = j < N ? wend[s] + d0 : -INFINITY;
+            vfin[s] = j < N ? (take ? wend[1][s] : wend[0][s]) + dtake : -INFINITY;
             vj[j] = vfin[s];
+          }
+          if (threadIdx.x == 0) {
+            sel_hyp[c] = take;
+            sel_from[c] = g + 1;
           }
           jumped = true;
           t0 = target;
@@ -723,6 +909,20 @@ void k_vit_wide_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, int NP, con
     logprob[id] = v[last];
     if (stats) { atomicAdd(&stats[0], n_block); atomicAdd(&stats[1], n_jump); }
   }
+}
+
+// the second set of traceback bytes where the chain adopted hypothesis 1: one workgroup per chunk
+__global__ __launch_bounds__(256) void k_wide_tb_select(IntervalTab iv, VitChunks vc, int N, int TBW, uint8_t *tb,
+                                                        const uint8_t *__restrict__ tb2, const int64_t *sel_from,
+                                                        const int *sel_hyp) {
+  const int c = blockIdx.x;
+  if (sel_hyp[c] != 1) return;
+  const int id = vc.iv[c];
+  const int64_t p0 = iv.pos0[id], ct0 = vc.t0[c];
+  const int64_t from = max(sel_from[c], ct0 + (int64_t)vc.ties[(int64_t)c * TEHMM_SPEC_MAXT]);
+  const int64_t n = (ct0 + vc.CS - from) * (int64_t)TBW;
+  const int64_t o = (p0 + from) * (int64_t)TBW;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) tb[o + i] = tb2[o + i];
 }
 
 }  // namespace tehmm

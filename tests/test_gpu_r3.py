@@ -419,3 +419,59 @@ def test_wide_posterior_impossible_rows_fall_back(monkeypatch):
     assert_array_equal(out["1"][0], out["0"][0])
     assert_array_equal(out["1"][1], out["0"][1])
     assert np.isfinite(out["1"][0][0])
+
+
+# ------------------------------------------------------------------ chunk-parallel exact Viterbi, 64 <= N <= 128
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("N,with_ratio,kw", [
+    (100, True, {}),                        # BASELINE configs[4]: 100 states, segment ratios on both sides of 1
+    (100, False, {}),
+    (64, True, {}), (77, False, {}), (128, True, {}),
+    (100, True, dict(stay=0.995)),          # sticky
+    (90, True, dict(sparse=0.5)),           # -1e100 transitions
+])
+def test_wide_viterbi_chunk_parallel_bit_exact(monkeypatch, N, with_ratio, kw):
+    """decode (basehmm.py:301-330 over _hmm._viterbi, _hmm.pyx:201-259, incl. the from-state-0 ratio quirk Q4) for
+    64..128 states on the chunk-parallel path of tehmm_wide.hip.h -- plain P0, quantised P2 carrying both rounding-tie
+    hypotheses, exact four-wave chain with verified jumps: state paths and scores bit for bit against the CPU oracle,
+    chunks really jumped over, and the same on the sequential kernel."""
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    from oracle import oracle
+    for k in ("TEHMM_WIDE_VIT", "TEHMM_WIDE_CP", "TEHMM_SPEC_CHUNK"):
+        monkeypatch.delenv(k, raising=False)
+    model = synth.make_model(N, synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=5 + N, **kw)
+    rs = np.random.RandomState(N)
+    lens = [int(x) for x in rs.randint(30000, 90000, size=3)] + [1, 70, 1500, 2048, 5000]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    T = int(offs[-1])
+    obs = synth.sample_obs(model, T, seed=7, missing=0.02)
+    ratios = None
+    if with_ratio:
+        ratios = synth.random_ratios(T, seed=N)
+        ratios[rs.rand(T) < 0.4] = 1.0
+        idx = rs.randint(0, T, size=max(1, T // 500))
+        ratios[idx] = rs.randint(200, 5000, size=idx.size).astype(np.float64) / 20.0
+        ratios = np.ascontiguousarray(ratios)
+    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, 1.0, model.symbols_per_track)
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TEHMM_WIDE_VIT", mode)
+        hb = HipBatch(obs, offs, ratios)
+        res = hm.eval(hb, viterbi=True, posterior=False, use_ratios=with_ratio)
+        tm = hb.timing()
+        got[mode] = (res["viterbi_logprob"].copy(), np.array(hb.paths()))
+        hb.close()
+        if mode == "1":
+            assert tm.get("count:viterbi_chunk_jumps", 0) > 0
+            print("wide Viterbi N=%d ratio=%d: %d exact blocks of 16, %d chunk jumps, %d positions"
+                  % (N, with_ratio, tm["count:viterbi_exact_blocks"], tm["count:viterbi_chunk_jumps"], T))
+        else:
+            assert "count:viterbi_chunk_jumps" not in tm
+    for i in range(len(lens)):
+        a, b = int(offs[i]), int(offs[i + 1])
+        lp_o, path_o = oracle.decode(obs[a:b], model.log_probs, model.log_startprob, model.log_transmat, 1.0,
+                                     None if ratios is None else ratios[a:b])
+        for mode in ("1", "0"):
+            assert_array_equal(got[mode][1][a:b], path_o)
+            assert got[mode][0][i] == lp_o
