@@ -208,6 +208,7 @@ struct WideWork {
   // chunk-parallel exact Viterbi (k_vit_wide_spec / k_vit_wide_fix)
   DBuf<double> BL;                 // log emission rows [internal position][128]
   DBuf<double> rows2;              // recorded rows of the second tie hypothesis
+  DBuf<double> pre;                // [hypothesis][chunk][NP] vectors the quantised pass enters its chunks with
   DBuf<uint8_t> tb2;               // its traceback bytes
   DBuf<int64_t> sel_from;          // per chunk: first position the chain adopted from the quantised pass
   DBuf<int> sel_hyp;               // per chunk: which hypothesis it adopted (-1: none)
@@ -1629,13 +1630,20 @@ static int posterior_wide_cp(tehmm_batch *b, const tehmm_model *m, const Interva
 // ---- chunk-parallel exact Viterbi for 64 <= N <= 128 (tehmm_wide.hip.h) -------------------------------------------
 // *done = true: traceback bytes, last states and scores of the batch are in place (the generic traceback follows);
 // false: the caller runs the sequential kernels
+static int wide_vit_warmup(int CS) {    // positions the quantised pass runs ahead of its chunk (<= chunk length)
+  const char *s = std::getenv("TEHMM_WIDE_VIT_WARMUP");
+  return std::min(CS, std::max(0, s ? std::atoi(s) : 64));
+}
 static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em, bool ratio,
                            hipStream_t st, bool *done) {
   *done = false;
   const char *ws = std::getenv("TEHMM_WIDE_VIT");
   if (ws && std::atoi(ws) == 0) return TEHMM_OK;
-  const int CS = spec_chunk_size();
-  if (m->N < 64 || m->N > 128 || CS <= 0 || b->total < 2 * (int64_t)CS) return TEHMM_OK;
+  // chunks of 256 positions unless TEHMM_SPEC_CHUNK says otherwise: a chunk that crosses into the next binade is walked
+  // exactly up to the crossing (half a chunk on average, seven crossings per 100 kb interval), an interval's first
+  // chunk always (measured, 2 Mb in 20 intervals at 100 states: 1024 -> 55 ms, 512 -> 38, 256 -> 32, 128 -> 31)
+  const int CS = std::getenv("TEHMM_SPEC_CHUNK") ? spec_chunk_size() : 256;
+  if (m->N < 64 || m->N > 128 || CS < 64 || b->total < 2 * (int64_t)CS) return TEHMM_OK;
   if (use_wide() == false || !(m->NP / 4 <= TEHMM_WIDE_QM && wide_lds_bytes(em.lds_rows, m->NP) <= 160 * 1024)) return TEHMM_OK;
   int rc = spec_prepare(b, m, CS);
   if (rc) return rc;
@@ -1645,6 +1653,7 @@ static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalT
   if (nc <= 0) return TEHMM_OK;
   HIPCHK(w.BL.ensure((size_t)b->total_pad * TEHMM_WIDE_S + TEHMM_WIDE_S));
   HIPCHK(w.rows2.ensure((size_t)nc * (CS / TEHMM_VROW) * m->NP + 1));
+  HIPCHK(w.pre.ensure((size_t)2 * nc * m->NP + 1));
   HIPCHK(w.tb2.ensure((size_t)(b->total_pad + 1) * b->TBW));
   HIPCHK(w.sel_from.ensure((size_t)nc + 1));
   HIPCHK(w.sel_hyp.ensure((size_t)nc + 1));
@@ -1669,12 +1678,12 @@ static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalT
       allow_lds(k_vit_wide_spec<false, true>, lds);
       hipLaunchKernelGGL((k_vit_wide_spec<false, true>), dim3(nwg), dim3(512), lds, st, iv, vc, m->N, m->NP,
                          (const double *)m->lt.p, (const double *)w.BL.p, (const double *)b->ratios.p,
-                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, b->tb.p, w.tb2.p, w.rows2.p);
+                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, b->tb.p, w.tb2.p, w.rows2.p, wide_vit_warmup(CS), w.pre.p);
     } else {
       allow_lds(k_vit_wide_spec<false, false>, lds);
       hipLaunchKernelGGL((k_vit_wide_spec<false, false>), dim3(nwg), dim3(512), lds, st, iv, vc, m->N, m->NP,
                          (const double *)m->lt.p, (const double *)w.BL.p, (const double *)nullptr,
-                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, b->tb.p, w.tb2.p, w.rows2.p);
+                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, b->tb.p, w.tb2.p, w.rows2.p, wide_vit_warmup(CS), w.pre.p);
     }
     w.h_gain.resize((size_t)nc);
     HIPCHK(hipMemcpyAsync(w.h_gain.data(), sw.gain.p, (size_t)nc * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1699,7 +1708,7 @@ static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalT
   HIPCHK(hipMemcpyAsync(sw.e.p, w.h_e.data(), (size_t)nc * sizeof(int), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemsetAsync(sw.ok.p, 0, (size_t)nc * sizeof(int), st));
   HIPCHK(hipMemsetAsync(sw.ntie.p, 0, (size_t)nc * sizeof(int), st));
-  HIPCHK(hipMemsetAsync(sw.stats.p, 0, 2 * sizeof(int), st));
+  HIPCHK(hipMemsetAsync(sw.stats.p, 0, 8 * sizeof(int), st));
   HIPCHK(hipMemsetAsync(w.sel_hyp.p, 0xff, ((size_t)nc + 1) * sizeof(int), st));
   if (nwg2 > 0) {
     HIPCHK(w.wk_c.ensure(w.h_wkc.size() + 8));
@@ -1710,12 +1719,12 @@ static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalT
       allow_lds(k_vit_wide_spec<true, true>, lds);
       hipLaunchKernelGGL((k_vit_wide_spec<true, true>), dim3(nwg2), dim3(512), lds, st, iv, vc, m->N, m->NP,
                          (const double *)m->lt.p, (const double *)w.BL.p, (const double *)b->ratios.p,
-                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, b->tb.p, w.tb2.p, w.rows2.p);
+                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, b->tb.p, w.tb2.p, w.rows2.p, wide_vit_warmup(CS), w.pre.p);
     } else {
       allow_lds(k_vit_wide_spec<true, false>, lds);
       hipLaunchKernelGGL((k_vit_wide_spec<true, false>), dim3(nwg2), dim3(512), lds, st, iv, vc, m->N, m->NP,
                          (const double *)m->lt.p, (const double *)w.BL.p, (const double *)nullptr,
-                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, b->tb.p, w.tb2.p, w.rows2.p);
+                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, b->tb.p, w.tb2.p, w.rows2.p, wide_vit_warmup(CS), w.pre.p);
     }
   }
   // the exact chain
@@ -1724,12 +1733,14 @@ static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalT
     allow_lds(k_vit_wide_fix<true>, ldsf);
     hipLaunchKernelGGL((k_vit_wide_fix<true>), dim3(b->n), dim3(256), ldsf, st, iv, em, vc, m->N, m->NP, (const double *)m->lt.p,
                        (const double *)m->pi.p, (const double *)b->ratios.p, b->TBW, b->tb.p, b->last_state.p, b->vit_lp.p,
-                       sw.stats.p, (const double *)w.rows2.p, (const double *)w.BL.p, w.sel_from.p, w.sel_hyp.p);
+                       sw.stats.p, (const double *)w.rows2.p, (const double *)w.BL.p, w.sel_from.p, w.sel_hyp.p,
+                       (const double *)w.pre.p);
   } else {
     allow_lds(k_vit_wide_fix<false>, ldsf);
     hipLaunchKernelGGL((k_vit_wide_fix<false>), dim3(b->n), dim3(256), ldsf, st, iv, em, vc, m->N, m->NP, (const double *)m->lt.p,
                        (const double *)m->pi.p, (const double *)nullptr, b->TBW, b->tb.p, b->last_state.p, b->vit_lp.p,
-                       sw.stats.p, (const double *)w.rows2.p, (const double *)w.BL.p, w.sel_from.p, w.sel_hyp.p);
+                       sw.stats.p, (const double *)w.rows2.p, (const double *)w.BL.p, w.sel_from.p, w.sel_hyp.p,
+                       (const double *)w.pre.p);
   }
   hipLaunchKernelGGL(k_wide_tb_select, dim3(nc), dim3(256), 0, st, iv, vc, m->N, b->TBW, b->tb.p, (const uint8_t *)w.tb2.p,
                      (const int64_t *)w.sel_from.p, (const int *)w.sel_hyp.p);
@@ -1750,6 +1761,12 @@ static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalT
     }
     std::fprintf(stderr, "[tehmm wide vit] chunks %d, speculated %d, usable %d, tie positions %ld, adopted h0 %d h1 %d none %d\n", nc,
                  n_spec, n_ok, ties, n_sel[0], n_sel[1], n_sel[2]);
+    {
+      int st8[8];
+      HIPCHK(hipMemcpy(st8, sw.stats.p, sizeof(st8), hipMemcpyDeviceToHost));
+      std::fprintf(stderr, "  failed checks %d: not in binade %d, leaves binade %d, no constant with matching parity %d\n", st8[2], st8[3],
+                   st8[4], st8[5]);
+    }
     for (int e = 10; e < 30; ++e) {
       int ne = 0, nok = 0, nsel = 0;
       long nt = 0;

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks
                                                        const double *__restrict__ g_lt, const double *__restrict__ BL,
                                                        const double *__restrict__ tratios, const int *__restrict__ wk_c,
                                                        const int *__restrict__ wk_e, int TBW, uint8_t *tb, uint8_t *tb2,
-                                                       double *rows2) {
+                                                       double *rows2, int WU, double *pre) {
   extern __shared__ double wsm[];
   double *tq = wsm;
   volatile int *tflag = (volatile int *)(wsm + (size_t)N * TEHMM_WIDE_S);
@@ -431,10 +431,14 @@ __global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks
   const double lt00 = g_lt[0];
   const double lt00q = QUANT ? (lt00 + M) - M : lt00;
   if (QUANT && RATIO && (fabs(lt00 - lt00q) == half_u || !(fabs(lt00) < zlim))) bad = true;
+  // QUANT: the pass starts WU positions BEFORE its chunk (a speculated chunk is never an interval's first), so that
+  // by the chunk's first position it has forgotten its zero start: `pre` [hypothesis][chunk][NP] keeps the vector
+  // at position t0 - 1, against which the chain can verify the chunk without walking a single step of it
+  const int s_first = QUANT ? -WU : 0;
   const double *bp = BL + (p0 + t0) * TEHMM_WIDE_S;
-  double bn0 = bp[lane], bn1 = bp[lane + 64];
+  double bn0 = bp[(int64_t)s_first * TEHMM_WIDE_S + lane], bn1 = bp[(int64_t)s_first * TEHMM_WIDE_S + lane + 64];
   const int n0 = min(N, 64);
-  for (int s = 0; s < len; ++s) {
+  for (int s = s_first; s < len; ++s) {
     const int64_t t = t0 + s;
     const double b0 = bn0, b1 = bn1;
     if (s + 1 < len) {
@@ -497,14 +501,33 @@ __global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks
         x0 += QUANT ? 128.0 * dz0 : dz0;
         x1 += QUANT ? 128.0 * dz1 : dz1;
       }
-#pragma unroll 4
-      for (int f = 1; f < n0; ++f) {
+      // eight from-states at a time: their sixteen table entries are requested before the first is used (left as
+      // a rolled loop every iteration waits for its own two LDS reads: 11 us per step)
+      auto oct = [&](const double wreg, int fb, int lb) {
+        double ta[8], tc[8], sv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          ta[i] = tq[(fb + i) * TEHMM_WIDE_S + lane];
+          tc[i] = tq[(fb + i) * TEHMM_WIDE_S + lane + 64];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sv[i] = wide_readlane(wreg, lb + i);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          x0 = fmax(x0, sv[i] + ta[i]);
+          x1 = fmax(x1, sv[i] + tc[i]);
+        }
+      };
+      int f = 1;
+      for (; f + 8 <= n0; f += 8) oct(W0[h], f, f);
+      for (; f < n0; ++f) {
         const double sv = wide_readlane(W0[h], f);
         x0 = fmax(x0, sv + tq[f * TEHMM_WIDE_S + lane]);
         x1 = fmax(x1, sv + tq[f * TEHMM_WIDE_S + lane + 64]);
       }
-#pragma unroll 4
-      for (int f = 64; f < N; ++f) {
+      f = 64;
+      for (; f + 8 <= N; f += 8) oct(W1[h], f, f - 64);
+      for (; f < N; ++f) {
         const double sv = wide_readlane(W1[h], f - 64);
         x0 = fmax(x0, sv + tq[f * TEHMM_WIDE_S + lane]);
         x1 = fmax(x1, sv + tq[f * TEHMM_WIDE_S + lane + 64]);
@@ -528,6 +551,51 @@ __global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks
         W0[h] = (x0 + b0) + add0;
         W1[h] = (x1 + b1) + add1;
       }
+    };
+    // ---- both hypotheses, no tie at this position: one pass over the table for the two vectors (the pass is bound
+    // by LDS bandwidth: 100 KB of table per step and wave)
+    auto fast_both = [&]() {
+      const double sa = wide_readlane(W0[0], 0), sb = wide_readlane(W0[H - 1], 0);
+      const double t00 = tq[lane], t01 = tq[lane + 64];
+      double xa0 = sa + t00, xa1 = sa + t01, xb0 = sb + t00, xb1 = sb + t01;
+      if (RATIO) {
+        xa0 += 128.0 * dz0; xa1 += 128.0 * dz1;
+        xb0 += 128.0 * dz0; xb1 += 128.0 * dz1;
+      }
+      auto oct = [&](const double wa, const double wb, int fb, int lb) {
+        double ta[8], tc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          ta[i] = tq[(fb + i) * TEHMM_WIDE_S + lane];
+          tc[i] = tq[(fb + i) * TEHMM_WIDE_S + lane + 64];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const double va = wide_readlane(wa, lb + i), vb = wide_readlane(wb, lb + i);
+          xa0 = fmax(xa0, va + ta[i]);
+          xa1 = fmax(xa1, va + tc[i]);
+          xb0 = fmax(xb0, vb + ta[i]);
+          xb1 = fmax(xb1, vb + tc[i]);
+        }
+      };
+      auto one = [&](const double wa, const double wb, int f, int l) {
+        const double ta = tq[f * TEHMM_WIDE_S + lane], tc = tq[f * TEHMM_WIDE_S + lane + 64];
+        const double va = wide_readlane(wa, l), vb = wide_readlane(wb, l);
+        xa0 = fmax(xa0, va + ta);
+        xa1 = fmax(xa1, va + tc);
+        xb0 = fmax(xb0, vb + ta);
+        xb1 = fmax(xb1, vb + tc);
+      };
+      int f = 1;
+      for (; f + 8 <= n0; f += 8) oct(W0[0], W0[H - 1], f, f);
+      for (; f < n0; ++f) one(W0[0], W0[H - 1], f, f);
+      f = 64;
+      for (; f + 8 <= N; f += 8) oct(W1[0], W1[H - 1], f, f - 64);
+      for (; f < N; ++f) one(W1[0], W1[H - 1], f, f - 64);
+      W0[0] = xa0 + 128.0 * (bq0 + add0);
+      W1[0] = xa1 + 128.0 * (bq1 + add1);
+      W0[H - 1] = xb0 + 128.0 * (bq0 + add0);
+      W1[H - 1] = xb1 + 128.0 * (bq1 + add1);
     };
     // ---- one hypothesis at a tie position: every candidate rounded half-to-even on its own parity
     auto slow = [&](auto hc) {
@@ -572,6 +640,7 @@ __global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks
     // ---- index extraction, traceback bytes, range check of one hypothesis
     auto finish = [&](auto hc, uint8_t *tbo) {
       constexpr int h = decltype(hc)::value;
+      const bool wr = s >= 0;
       // W = 128 (new value - base) + (127 - first arg-max) u, exact;  W + CM has exponent e, its low seven mantissa
       // bits are W / u mod 128
       const double x0 = W0[h], x1 = W1[h];
@@ -579,8 +648,8 @@ __global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks
       const unsigned l0 = (unsigned)__double2loint(y0), l1 = (unsigned)__double2loint(y1);
       W0[h] = x0 > -INFINITY ? __hiloint2double(__double2hiint(y0), (int)(l0 & ~127u)) - CM : -INFINITY;
       W1[h] = x1 > -INFINITY ? __hiloint2double(__double2hiint(y1), (int)(l1 & ~127u)) - CM : -INFINITY;
-      if (live0) tbo[(p0 + t) * TBW + lane] = x0 > -INFINITY ? (uint8_t)(~l0 & 127u) : (uint8_t)0;
-      if (live1) tbo[(p0 + t) * TBW + lane + 64] = x1 > -INFINITY ? (uint8_t)(~l1 & 127u) : (uint8_t)0;
+      if (wr && live0) tbo[(p0 + t) * TBW + lane] = x0 > -INFINITY ? (uint8_t)(~l0 & 127u) : (uint8_t)0;
+      if (wr && live1) tbo[(p0 + t) * TBW + lane + 64] = x1 > -INFINITY ? (uint8_t)(~l1 & 127u) : (uint8_t)0;
       bad = bad | (live0 && W0[h] <= wlim && W0[h] > -INFINITY) | (live1 && W1[h] <= wlim && W1[h] > -INFINITY);
     };
     // re-base (every 8 steps: at 128 x the range holds 2^(e-7) log units, a position costs ~25) and record
@@ -611,11 +680,13 @@ __global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks
       continue;
     }
     if (anytie) {
-      first_tie = min(first_tie, s);
-      ++nt;
+      first_tie = min(first_tie, max(s, 0));
+      nt += s >= 0;
       slow(H0{});
       slow(H1{});
       diverged = true;
+    } else if (diverged && n_tt == 0) {
+      fast_both();
     } else {
       fast(H0{});
       if (diverged) fast(H1{});
@@ -626,7 +697,7 @@ __global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks
       rebase(H0{});
       if (diverged) rebase(H1{});
     }
-    if ((s & (TEHMM_VROW - 1)) == TEHMM_VROW - 1) {
+    if (s >= 0 && (s & (TEHMM_VROW - 1)) == TEHMM_VROW - 1) {
       record(H0{}, vc.rows);
       if (diverged) record(H1{}, rows2);
     }
@@ -635,7 +706,17 @@ __global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks
       W1[H - 1] = W1[0];
       base[H - 1] = base[0];
       pb[H - 1] = pb[0] ^ 1;
-      if ((s & (TEHMM_VROW - 1)) == TEHMM_VROW - 1) {
+    }
+    if (s == -1) {                        // the vector the chunk is entered with, both hypotheses
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        double *row = pre + ((int64_t)h * vc.n + c) * NP;
+        row[lane] = live0 ? W0[h] * 0.0078125 + base[h] : -INFINITY;
+        if (lane + 64 < NP) row[lane + 64] = live1 ? W1[h] * 0.0078125 + base[h] : -INFINITY;
+      }
+    }
+    if (!diverged) {
+      if (s >= 0 && (s & (TEHMM_VROW - 1)) == TEHMM_VROW - 1) {
         double *row = rows2 + ((int64_t)c * (CS / TEHMM_VROW) + s / TEHMM_VROW) * NP;
         row[lane] = live0 ? W0[0] * 0.0078125 + base[0] : -INFINITY;
         if (lane + 64 < NP) row[lane + 64] = live1 ? W1[0] * 0.0078125 + base[0] : -INFINITY;
@@ -669,7 +750,8 @@ template <bool RATIO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_vit_wide_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, int NP, const double *g_lt, const double *g_pi,
                     const double *tratios, int TBW, uint8_t *tb, int *last_state, double *logprob, int *stats,
-                    const double *__restrict__ rows2, const double *__restrict__ BL, int64_t *sel_from, int *sel_hyp) {
+                    const double *__restrict__ rows2, const double *__restrict__ BL, int64_t *sel_from, int *sel_hyp,
+                    const double *__restrict__ pre) {
   extern __shared__ double sm[];
   constexpr int W = TEHMM_WIDE_W, QM = TEHMM_WIDE_QM;
   double *ring = sm;
@@ -708,7 +790,100 @@ void k_vit_wide_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, int NP, con
   int64_t t0 = 0, since = 0;                        // block start; where the exact run (re)started
   double bnx[2] = {0.0, 0.0};                       // log row of position tnx, requested a step ahead
   int64_t tnx = -1;
+  // Does the current vector (vfin, position `at`) equal a recorded row of chunk c's quantised pass up to ONE constant
+  // -- for the hypothesis whose parity that constant has --, is every value in the chunk's binade and (by the chunk's
+  // P0 gain) does it stay there up to the chunk end?  Then the chunk is adopted to its end: V = last row + constant
+  // (exact: multiples of u inside one binade).  Every wave holds the whole vector: all four decide alike.
+  auto adopt = [&](int64_t c, int e, const double (&wrow)[2][2], const double (&wend)[2][2], double span, int64_t from) {
+    double vmn = INFINITY;
+    bool inb = true;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int j = lane + 64 * s;
+      if (j < N && vfin[s] > -INFINITY) {
+        vmn = fmin(vmn, vfin[s]);
+        inb = inb && exp_of(-vfin[s]) == e + 1;            // 2^e <= |v| < 2^(e+1)
+      }
+    }
+    const double vlow = wave_min_f64(vmn) - span;
+    const bool common = __all(inb) && vlow > -INFINITY && exp_of(-vlow) == e + 1;
+    int take = -1;
+    double dtake = 0.0;
+    const double i2u = ldexp(1.0, 51 - e);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      double dmx = -INFINITY;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int j = lane + 64 * s;
+        const bool both_dead = vfin[s] == -INFINITY && wrow[h][s] == -INFINITY;
+        if (j < N && !both_dead) dmx = fmax(dmx, vfin[s] - wrow[h][s]);
+      }
+      const double d0 = wave_max_f64(dmx);
+      bool okl = true;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int j = lane + 64 * s;
+        const bool both_dead = vfin[s] == -INFINITY && wrow[h][s] == -INFINITY;
+        if (j < N && !both_dead) okl = okl && (vfin[s] - wrow[h][s]) == d0;
+      }
+      const bool fin = d0 == d0 && d0 > -INFINITY && d0 < INFINITY;
+      const bool odd = fin && __builtin_amdgcn_fract(d0 * i2u) != 0.0;
+      if (take < 0 && fin && __all(okl) && (int)odd == h) {
+        take = h;
+        dtake = d0;
+      }
+    }
+    if (!(common && take >= 0)) {
+#ifdef TEHMM_WIDE_DEBUG
+      if (threadIdx.x == 0 && stats) {
+        atomicAdd(&stats[2], 1);
+        if (!__all(inb)) atomicAdd(&stats[3], 1);
+        else if (!common) atomicAdd(&stats[4], 1);
+        if (take < 0) atomicAdd(&stats[5], 1);
+      }
+#endif
+      return false;
+    }
+    double *vj = vmine + cur * W;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int j = lane + 64 * s;
+      vfin[s] = j < N ? (take ? wend[1][s] : wend[0][s]) + dtake : -INFINITY;
+      vj[j] = vfin[s];
+    }
+    if (threadIdx.x == 0) {
+      sel_hyp[c] = take;
+      sel_from[c] = from;
+    }
+    ++n_jump;
+    return true;
+  };
   while (t0 < T) {
+    // ---- at a chunk's first position: the quantised pass warmed up before the chunk, its vector at t0 - 1 (`pre`)
+    // can be compared with the chain's right away -- a verified chunk costs the chain no step at all
+    {
+      const int64_t c = cfirst + t0 / CS;
+      const int64_t ct0 = vc.t0[c];
+      const int e = vc.e[c];
+      if (t0 == ct0 && t0 > 0 && e != TEHMM_SPEC_NONE && vc.ok[c] != 0 && seen) {
+        double wrow[2][2], wend[2][2];
+        const int64_t eo = ((c * (CS / TEHMM_VROW)) + (CS / TEHMM_VROW - 1)) * NP;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int j = lane + 64 * s;
+          wrow[0][s] = j < N ? pre[c * NP + j] : -INFINITY;
+          wrow[1][s] = j < N ? pre[((int64_t)vc.n + c) * NP + j] : -INFINITY;
+          wend[0][s] = j < N ? vc.rows[eo + j] : -INFINITY;
+          wend[1][s] = j < N ? rows2[eo + j] : -INFINITY;
+        }
+        if (adopt(c, e, wrow, wend, fabs(vc.gain[c]) * 1.01 + 256.0, ct0)) {
+          t0 = ct0 + CS;
+          since = t0;
+          continue;
+        }
+      }
+    }
     ++n_block;
     const int np = (int)min((int64_t)TEHMM_PB, T - t0);
     const bool use_ring = !seen;                    // (uniform: every wave walks the leading rows alike)
@@ -827,65 +1002,10 @@ void k_vit_wide_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, int NP, con
       }
       cur ^= 1;
       if (do_check && p == pg) {
-        // verified iff V - W is one constant over the live states (for the hypothesis whose parity that constant
-        // has), every V is in the binade the chunk was quantised for, and (by the chunk's P0 gain) stays in it up
-        // to the chunk end.  Every wave holds the whole vector: all four take the same decision.
-        double vmn = INFINITY;
-        bool inb = true;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int j = lane + 64 * s;
-          if (j < N && vfin[s] > -INFINITY) {
-            vmn = fmin(vmn, vfin[s]);
-            inb = inb && exp_of(-vfin[s]) == e + 1;            // 2^e <= |v| < 2^(e+1)
-          }
-        }
-        const double vlow = wave_min_f64(vmn) - span;
-        const bool common = __all(inb) && vlow > -INFINITY && exp_of(-vlow) == e + 1;
-        int take = -1;
-        double dtake = 0.0;
-        const double i2u = ldexp(1.0, 51 - e);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          double dmx = -INFINITY;
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const int j = lane + 64 * s;
-            const bool both_dead = vfin[s] == -INFINITY && wrow[h][s] == -INFINITY;
-            if (j < N && !both_dead) dmx = fmax(dmx, vfin[s] - wrow[h][s]);
-          }
-          const double d0 = wave_max_f64(dmx);
-          bool okl = true;
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const int j = lane + 64 * s;
-            const bool both_dead = vfin[s] == -INFINITY && wrow[h][s] == -INFINITY;
-            if (j < N && !both_dead) okl = okl && (vfin[s] - wrow[h][s]) == d0;
-          }
-          const bool fin = d0 == d0 && d0 > -INFINITY && d0 < INFINITY;
-          const bool odd = fin && __builtin_amdgcn_fract(d0 * i2u) != 0.0;
-          if (take < 0 && fin && __all(okl) && (int)odd == h) {
-            take = h;
-            dtake = d0;
-          }
-        }
-        if (common && take >= 0) {
-          // V at the chunk's last position (exact: both multiples of u inside one binade)
-          double *vj = vmine + cur * W;
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const int j = lane + 64 * s;
-            vfin[s] = j < N ? (take ? wend[1][s] : wend[0][s]) + dtake : -INFINITY;
-            vj[j] = vfin[s];
-          }
-          if (threadIdx.x == 0) {
-            sel_hyp[c] = take;
-            sel_from[c] = g + 1;
-          }
+        if (adopt(c, e, wrow, wend, span, g + 1)) {
           jumped = true;
           t0 = target;
           since = target;
-          ++n_jump;
           break;
         }
       }
