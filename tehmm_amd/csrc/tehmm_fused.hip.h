@@ -60,6 +60,9 @@ struct FusedGeom {
 #define TEHMM_FUSED_2W 36        // two waves per SIMD (256 registers each) up to this many padded states, one above
 #endif
 #define TEHMM_FUSED_BLKW 24      // index words per (item, block): SB = 24 / FKW steps per block
+#ifndef TEHMM_FUSED_NSLOT_CAP
+#define TEHMM_FUSED_NSLOT_CAP 64
+#endif
 
 struct FusedTab {
   const unsigned long long *rixx;   // [tiles][NB][SB][FKW][16]
@@ -188,7 +191,7 @@ __device__ __forceinline__ unsigned long long lds_read_u64(unsigned addr) {
 template <int NT, bool LOGDOM>
 struct EmisStream {
   using G = FusedGeom<NT>;
-  static constexpr int NSLOT = G::KS;
+  static constexpr int NSLOT = G::KS < TEHMM_FUSED_NSLOT_CAP ? G::KS : TEHMM_FUSED_NSLOT_CAP;
   static constexpr int NGS = NSLOT > 1 ? 2 : 1;  // global tracks of the fixed schedule (FusedTab::n_glb >= NGS)
   static constexpr int GF = NSLOT >= 8 ? 4 : NSLOT / 2;
   const FusedTab &ft;
@@ -224,6 +227,7 @@ struct EmisStream {
     wcur = word(ft.n_glb >> 2);
   }
   __device__ __forceinline__ void slot(int k) {
+    if (k >= NSLOT) return;
     const int il = ft.n_glb + k;                                // this slot's LDS track
     if (k > 0) fold(xc);                                        // requested by the previous slot
     if (k == GF && NSLOT > 1) {

@@ -1348,7 +1348,7 @@ static int fused_prepare(tehmm_batch *b, const tehmm_model *m, const IntervalTab
   // the fixed schedule of EmisStream: at least NGS tracks from the global table, then at least NSLOT from LDS;
   // the padding entries (cnt = 0) always read the identity row
   {
-    constexpr int NSLOT = NT / 4, NGS = NSLOT > 1 ? 2 : 1;
+    constexpr int NSLOT = EmisStream<NT, false>::NSLOT, NGS = EmisStream<NT, false>::NGS;
     int slot = 0;
     auto pad = [&]() { fo.order[slot] = 0; fo.base[slot] = 0; fo.cnt[slot] = 0; ++slot; };
     for (int k = 0; k < m->K; ++k)

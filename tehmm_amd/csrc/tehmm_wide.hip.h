@@ -379,11 +379,21 @@ __global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks
   // LDS behind the table: flag | number of tie entries | tie entries (from | to << 8 | parity of the lower neighbour << 16)
   volatile int *ntt = tflag + 1;
   volatile int *ttab = tflag + 2;
-  if (threadIdx.x == 0) { *tflag = 0; *ntt = 0; }
+  int *hbig = (int *)(tflag + 2 + TEHMM_WIDE_MAXTT);             // [4]: states with a "never" transition into them
+  if (threadIdx.x == 0) { *tflag = 0; *ntt = 0; hbig[0] = hbig[1] = hbig[2] = hbig[3] = 0; }
   __syncthreads();
+  const double zhuge = QUANT ? -ldexp(1.0, e + 1) : -INFINITY;
   for (int i = threadIdx.x; i < N * TEHMM_WIDE_S; i += blockDim.x) {
     const int f = i >> 7, j = i & 127;
-    const double z = j < N ? g_lt[(size_t)f * NP + j] : -INFINITY;
+    double z = j < N ? g_lt[(size_t)f * NP + j] : -INFINITY;
+    if (QUANT && z > -INFINITY && z <= zhuge) {
+      // a "never" transition (the reference's log(0) = -1e100): V[f] + z lies below everything a candidate with an
+      // ordinary transition reaches from inside the binade (V <= -2^e, z <= -2^(e+1), ordinary |z'| < 2^(e-1)), so it
+      // counts as -inf here -- as long as the state has such a candidate from a live state: a state that comes out
+      // at -inf although it has "never" transitions spoils the chunk (finish)
+      atomicOr(&hbig[j >> 5], 1 << (j & 31));
+      z = -INFINITY;
+    }
     double val = z;
     if (QUANT) {
       double q = (z + M) - M;
@@ -411,6 +421,8 @@ __global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks
   const int CS = vc.CS;
   const int len = (int)min((int64_t)CS, iv.len[id] - t0);     // (P0 also runs ragged tails; P2 only full chunks)
   const bool live0 = lane < N, live1 = lane + 64 < N;
+  const bool big0 = QUANT && ((hbig[lane >> 5] >> (lane & 31)) & 1) != 0;
+  const bool big1 = QUANT && ((hbig[2 + (lane >> 5)] >> (lane & 31)) & 1) != 0;
   constexpr int H = QUANT ? 2 : 1;
   double W0[H], W1[H], base[H];          // QUANT: 128 x (value - base) of the lane's two states, per hypothesis
   int pb[H];                             // parity of base / u, XOR the hypothesis
@@ -651,6 +663,7 @@ __global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks
       if (wr && live0) tbo[(p0 + t) * TBW + lane] = x0 > -INFINITY ? (uint8_t)(~l0 & 127u) : (uint8_t)0;
       if (wr && live1) tbo[(p0 + t) * TBW + lane + 64] = x1 > -INFINITY ? (uint8_t)(~l1 & 127u) : (uint8_t)0;
       bad = bad | (live0 && W0[h] <= wlim && W0[h] > -INFINITY) | (live1 && W1[h] <= wlim && W1[h] > -INFINITY);
+      bad = bad | (big0 && !(x0 > -INFINITY)) | (big1 && !(x1 > -INFINITY));
     };
     // re-base (every 8 steps: at 128 x the range holds 2^(e-7) log units, a position costs ~25) and record
     auto rebase = [&](auto hc) {

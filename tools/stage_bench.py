@@ -1,5 +1,5 @@
 """Stage timings of the fused eval in isolation: posterior only, Viterbi only, both (bench workload).
-usage: [STAGES=viterbi] [SINGLE=1] python tools/stage_bench.py [Mb]"""
+usage: [STAGES=viterbi] [SINGLE=1] [TRACKS=8,30,12,250g,250g] python tools/stage_bench.py [Mb]"""
 import os, sys, json
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,12 @@ from tehmm_amd.engine import HipBatch, HipModel
 
 mb = float(sys.argv[1]) if len(sys.argv) > 1 else 100.0
 dev = torch.device("cuda", 0)
-model = synth.make_model(int(os.environ.get("STATES", bench.N_STATES)), synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=0)
+syms, gauss = synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN
+if os.environ.get("TRACKS"):              # e.g. TRACKS=8,30,12,250g,250g  (g = gaussian bins)
+    ent = os.environ["TRACKS"].split(",")
+    syms = tuple(int(e.rstrip("g")) for e in ent)
+    gauss = tuple(i for i, e in enumerate(ent) if e.endswith("g"))
+model = synth.make_model(int(os.environ.get("STATES", bench.N_STATES)), syms, gauss, seed=0)
 total = int(mb * 1e6)
 lens = synth.interval_lengths(total, 200_000, 2_000_000, seed=1000)
 if os.environ.get("SINGLE"):              # one interval of `Mb` (BASELINE configs[1] geometry)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development check of the chunk-parallel exact Viterbi for 64 <= N <= 128 (tehmm_wide.hip.h) against the CPU oracle:
-python tools/wide_vit_check.py [N] [n_intervals] [interval_len] [ratio 0/1]"""
+[SPARSE=0.5] [STAY=0.995] [SEED=0] python tools/wide_vit_check.py [N] [n_intervals] [interval_len] [ratio 0/1]"""
 import os
 import sys
 import time
@@ -19,7 +19,12 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     L = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
     with_ratio = bool(int(sys.argv[4])) if len(sys.argv) > 4 else False
-    model = synth.make_model(N, synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=0)
+    kw = {}
+    if os.environ.get("SPARSE"):
+        kw["sparse"] = float(os.environ["SPARSE"])
+    if os.environ.get("STAY"):
+        kw["stay"] = float(os.environ["STAY"])
+    model = synth.make_model(N, synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=int(os.environ.get("SEED", 0)), **kw)
     rs = np.random.RandomState(3)
     lens = [L + int(rs.randint(-L // 3, L // 3)) for _ in range(n)] + [1, 70, 1500]
     offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
