@@ -215,6 +215,17 @@ struct WideWork {
   DBuf<int> wk_c, wk_e;            // work lists: 8 chunks of one binade per workgroup
   std::vector<int> h_wkc, h_wke, h_e;
   std::vector<double> h_gain;
+  // a posterior attempt in flight (posterior_wide_cp enqueued it, posterior_wide_finish checks its links)
+  bool pp_active = false;
+  int pp_Wu = 0;
+  int *h_flags = nullptr;          // pinned: impossible rows / failed links of the attempt
+  ~WideWork() { if (h_flags) (void)hipHostFree(h_flags); }
+  DBuf<uint8_t> tb1;               // traceback bytes of the quantised pass, hypothesis 0 (tb2: hypothesis 1)
+  DBuf<int> ready;                 // per chunk: the quantised pass is through with it (the chain polls, see k_vit_wide_fix)
+  DBuf<int64_t> hstop;             // per interval: where its first speculated chunk starts (the head ends)
+  DBuf<double> hvec;               // [n][NP] the chain's vector at hstop - 1 (phase 1 -> phase 2 of k_vit_wide_fix)
+  DBuf<int> hflag;
+  std::vector<int64_t> h_hstop;
 };
 
 struct tehmm_batch {
@@ -1538,11 +1549,71 @@ static void launch_wide_passes(tehmm_batch *b, const tehmm_model *m, const Inter
                      (const double *)w.E.p, (const float *)w.AL.p, b->post.p, w.pre_b.p, w.end_b.p);
 }
 
-// *done = true: posteriors and forward log-likelihoods of the batch are in place; false: the caller runs the
-// sequential kernels (short batches, a link that does not verify within the longest warm-up, impossible rows)
-static int posterior_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em, hipStream_t st,
-                             hipEvent_t mid, bool *done) {
+// One attempt of the chunk-parallel posterior with warm-up Wu, enqueued on st: passes, link checks, and the flags
+// (impossible rows, failed links) on their way to pinned host memory.
+static int wide_post_attempt(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, int Wu, hipStream_t st, hipEvent_t mid) {
+  WideWork &w = b->ww;
+  LaneGeom lg;
+  lg.item_iv = w.item_iv.p; lg.item_t0 = w.item_t0.p; lg.ifirst = w.ifirst.p;
+  lg.n_items = w.n_items; lg.n_groups = w.n_groups; lg.L = w.L;
+  const int NPW = w.NPW;
+  switch (NPW) {
+    case 80: launch_wide_passes<80>(b, m, iv, lg, Wu, st, mid); break;
+    case 96: launch_wide_passes<96>(b, m, iv, lg, Wu, st, mid); break;
+    case 112: launch_wide_passes<112>(b, m, iv, lg, Wu, st, mid); break;
+    default: launch_wide_passes<128>(b, m, iv, lg, Wu, st, mid); break;
+  }
+  hipLaunchKernelGGL(k_wide_links, dim3((w.n_items + 255) / 256), dim3(256), 0, st, iv, lg, m->N, NPW,
+                     (const double *)w.pre_f.p, (const double *)w.end_f.p, (const double *)w.pre_b.p,
+                     (const double *)w.end_b.p, w.lr.p, w.flags.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(w.h_flags, w.flags.p, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+  w.pp_Wu = Wu;
+  w.pp_active = true;
+  return TEHMM_OK;
+}
+
+// The attempt's verdict (waits for st): links that do not verify double the warm-up and run again, up to 1024
+// positions.  *done = true: posteriors and forward log-likelihoods of the batch are in place; false: the caller runs
+// the sequential kernels (a link that does not verify within the longest warm-up, impossible rows).
+static int posterior_wide_finish(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, hipStream_t st, hipEvent_t mid,
+                                 bool *done) {
   *done = false;
+  WideWork &w = b->ww;
+  if (!w.pp_active) return TEHMM_OK;
+  w.pp_active = false;
+  constexpr int kWuMax = 1024;
+  for (;;) {
+    HIPCHK(hipStreamSynchronize(st));
+    const int Wu = w.pp_Wu;
+    if (std::getenv("TEHMM_SPEC_DEBUG"))
+      std::fprintf(stderr, "[tehmm wide] NPW %d L %d Wu %d: impossible rows in %d items, failed links %d of %d items\n", w.NPW, w.L,
+                   Wu, w.h_flags[0], w.h_flags[1], w.n_items);
+    if (w.h_flags[0] > 0) return TEHMM_OK;             // impossible rows: the sequential kernels own their semantics
+    if (w.h_flags[1] == 0) break;
+    if (Wu >= kWuMax) return TEHMM_OK;                 // does not forget: sequential kernels
+    HIPCHK(hipMemsetAsync(w.flags.p, 0, 4 * sizeof(int), st));
+    if (int rc = wide_post_attempt(b, m, iv, std::min(kWuMax, 2 * Wu), st, mid)) return rc;
+    w.pp_active = false;
+  }
+  w.wu_ok = w.pp_Wu;
+  w.wu_model = m->uid;
+  w.wu_version = m->version;
+  LaneGeom lg;
+  lg.item_iv = w.item_iv.p; lg.item_t0 = w.item_t0.p; lg.ifirst = w.ifirst.p;
+  lg.n_items = w.n_items; lg.n_groups = w.n_groups; lg.L = w.L;
+  hipLaunchKernelGGL(k_wide_loglik, dim3((b->n + 63) / 64), dim3(64), 0, st, iv, lg, m->N, w.NPW, (const double *)w.end_f.p,
+                     (const double *)w.SL.p, (const double *)w.lr.p, b->fwd_lp.p);
+  *done = true;
+  return TEHMM_OK;
+}
+
+// Chunk-parallel posterior for 64 <= N <= 128: geometry, emission rows and the first attempt are ENQUEUED here
+// (*pending = true; nothing enqueued otherwise: short batches, TEHMM_WIDE_CP=0); posterior_wide_finish delivers the
+// verdict, so the exact Viterbi of the same evaluation can be enqueued in between and share the GPU with the passes.
+static int posterior_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em, hipStream_t st,
+                             hipEvent_t mid, bool *pending) {
+  *pending = false;
   const char *ws = std::getenv("TEHMM_WIDE_CP");
   if (ws && std::atoi(ws) == 0) return TEHMM_OK;
   if (m->N < 64 || m->N > 128 || b->total < 4096) return TEHMM_OK;
@@ -1551,6 +1622,7 @@ static int posterior_wide_cp(tehmm_batch *b, const tehmm_model *m, const Interva
   for (int sz : sizes)
     if (m->N <= sz) { NPW = sz; break; }
   WideWork &w = b->ww;
+  if (!w.h_flags) HIPCHK(hipHostMalloc((void **)&w.h_flags, 64, hipHostMallocDefault));
   // item length: enough items to give every SIMD a tile (1024 tiles of 16 items), 64 <= L <= 512, multiple of 32
   int L = (int)std::min<int64_t>(512, std::max<int64_t>(64, (b->total / (16 * 1024) + 31) & ~31));
   if (const char *ls = std::getenv("TEHMM_WIDE_SUB")) L = std::max(32, (std::atoi(ls) + 31) & ~31);
@@ -1588,41 +1660,14 @@ static int posterior_wide_cp(tehmm_batch *b, const tehmm_model *m, const Interva
   const EmisTab emg = without_lds_tables(em);
   HIPCHK(hipMemsetAsync(w.flags.p, 0, 4 * sizeof(int), st));
   hipLaunchKernelGGL(k_wide_emis, dim3((w.n_items + 3) / 4), dim3(256), 0, st, iv, emg, lg, m->N, NPW, w.E.p, w.ms.p, w.flags.p);
-  // warm-up: 128 positions, doubled until every link verifies (it may exceed the item length: the passes read the
-  // emission rows of the interval, not of the item); beyond 1024 the sequential kernels take over
+  // warm-up: 128 positions to begin with (it may exceed the item length: the passes read the emission rows of the
+  // interval, not of the item), or what the last evaluation with this model needed
   constexpr int kWuMax = 1024;
   int Wu = 128;
   if (const char *wus = std::getenv("TEHMM_LANE_WARMUP")) Wu = std::min(kWuMax, std::max(1, std::atoi(wus)));
   else if (w.wu_ok > 0 && w.wu_model == m->uid && w.wu_version == m->version) Wu = w.wu_ok;
-  for (;;) {
-    switch (NPW) {
-      case 80: launch_wide_passes<80>(b, m, iv, lg, Wu, st, mid); break;
-      case 96: launch_wide_passes<96>(b, m, iv, lg, Wu, st, mid); break;
-      case 112: launch_wide_passes<112>(b, m, iv, lg, Wu, st, mid); break;
-      default: launch_wide_passes<128>(b, m, iv, lg, Wu, st, mid); break;
-    }
-    hipLaunchKernelGGL(k_wide_links, dim3((w.n_items + 255) / 256), dim3(256), 0, st, iv, lg, m->N, NPW,
-                       (const double *)w.pre_f.p, (const double *)w.end_f.p, (const double *)w.pre_b.p,
-                       (const double *)w.end_b.p, w.lr.p, w.flags.p);
-    HIPCHK(hipGetLastError());
-    int flags[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpyAsync(flags, w.flags.p, sizeof(flags), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (std::getenv("TEHMM_SPEC_DEBUG"))
-      std::fprintf(stderr, "[tehmm wide] NPW %d L %d Wu %d: impossible rows in %d items, failed links %d of %d items\n", NPW, L, Wu,
-                   flags[0], flags[1], w.n_items);
-    if (flags[0] > 0) return TEHMM_OK;                 // impossible rows: the sequential kernels own their semantics
-    if (flags[1] == 0) break;
-    if (Wu >= kWuMax) return TEHMM_OK;                 // does not forget: sequential kernels
-    Wu = std::min(kWuMax, 2 * Wu);
-    HIPCHK(hipMemsetAsync(w.flags.p, 0, 4 * sizeof(int), st));
-  }
-  w.wu_ok = Wu;
-  w.wu_model = m->uid;
-  w.wu_version = m->version;
-  hipLaunchKernelGGL(k_wide_loglik, dim3((b->n + 63) / 64), dim3(64), 0, st, iv, lg, m->N, NPW, (const double *)w.end_f.p,
-                     (const double *)w.SL.p, (const double *)w.lr.p, b->fwd_lp.p);
-  *done = true;
+  if (int rc = wide_post_attempt(b, m, iv, Wu, st, mid)) return rc;
+  *pending = true;
   return TEHMM_OK;
 }
 
@@ -1635,7 +1680,7 @@ static int wide_vit_warmup(int CS) {    // positions the quantised pass runs ahe
   return std::min(CS, std::max(0, s ? std::atoi(s) : 64));
 }
 static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em, bool ratio,
-                           hipStream_t st, bool *done) {
+                           hipStream_t st, hipEvent_t ev_spec, bool *done) {
   *done = false;
   const char *ws = std::getenv("TEHMM_WIDE_VIT");
   if (ws && std::atoi(ws) == 0) return TEHMM_OK;
@@ -1655,6 +1700,8 @@ static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalT
   HIPCHK(w.rows2.ensure((size_t)nc * (CS / TEHMM_VROW) * m->NP + 1));
   HIPCHK(w.pre.ensure((size_t)2 * nc * m->NP + 1));
   HIPCHK(w.tb2.ensure((size_t)(b->total_pad + 1) * b->TBW));
+  HIPCHK(w.tb1.ensure((size_t)(b->total_pad + 1) * b->TBW));
+  HIPCHK(w.ready.ensure((size_t)nc + 1));
   HIPCHK(w.sel_from.ensure((size_t)nc + 1));
   HIPCHK(w.sel_hyp.ensure((size_t)nc + 1));
   VitChunks vc;
@@ -1674,7 +1721,20 @@ static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalT
     HIPCHK(w.wk_c.ensure(w.h_wkc.size() + 8));
     HIPCHK(w.wk_e.ensure(w.h_wke.size() + 8));
     HIPCHK(hipMemcpyAsync(w.wk_c.p, w.h_wkc.data(), w.h_wkc.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    if (ratio) {
+    const char *pf = std::getenv("TEHMM_WIDE_P0F");
+    if (!(pf && std::atoi(pf) == 0)) {
+      // packed floats (k_vit_wide_gain): the gains only place the binades
+      const size_t ldsg = (size_t)m->N * 64 * sizeof(float2);
+      if (ratio) {
+        allow_lds(k_vit_wide_gain<true>, ldsg);
+        hipLaunchKernelGGL((k_vit_wide_gain<true>), dim3(nwg), dim3(512), ldsg, st, iv, vc, m->N, m->NP, (const double *)m->lt.p,
+                           (const double *)w.BL.p, (const double *)b->ratios.p);
+      } else {
+        allow_lds(k_vit_wide_gain<false>, ldsg);
+        hipLaunchKernelGGL((k_vit_wide_gain<false>), dim3(nwg), dim3(512), ldsg, st, iv, vc, m->N, m->NP, (const double *)m->lt.p,
+                           (const double *)w.BL.p, (const double *)nullptr);
+      }
+    } else if (ratio) {
       allow_lds(k_vit_wide_spec<false, true>, lds);
       hipLaunchKernelGGL((k_vit_wide_spec<false, true>), dim3(nwg), dim3(512), lds, st, iv, vc, m->N, m->NP,
                          (const double *)m->lt.p, (const double *)w.BL.p, (const double *)b->ratios.p,
@@ -1694,7 +1754,12 @@ static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalT
   std::vector<int> order;
   for (int c = 0; c < nc; ++c)
     if (w.h_e[(size_t)c] != TEHMM_SPEC_NONE) order.push_back(c);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int c2) { return w.h_e[(size_t)a] < w.h_e[(size_t)c2]; });
+  // (binade, position in the interval): co-resident waves share one quantised table, and every interval's chain --
+  // which may follow the pass while it runs -- finds its next chunk done early
+  std::stable_sort(order.begin(), order.end(), [&](int a, int c2) {
+    if (w.h_e[(size_t)a] != w.h_e[(size_t)c2]) return w.h_e[(size_t)a] < w.h_e[(size_t)c2];
+    return sw.h_t0[(size_t)a] < sw.h_t0[(size_t)c2];
+  });
   w.h_wkc.clear();
   w.h_wke.clear();
   for (size_t i = 0; i < order.size();) {
@@ -1705,11 +1770,57 @@ static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalT
     for (; k < 8; ++k) w.h_wkc.push_back(-1);
   }
   const int nwg2 = (int)w.h_wke.size();
+  // every interval's head -- what lies before its first speculated chunk -- is walked by the exact chain on a side
+  // stream WHILE the quantised pass runs (phase 1 of k_vit_wide_fix); the chain proper resumes behind it (phase 2)
+  const char *hds = std::getenv("TEHMM_WIDE_HEAD");
+  const bool head = !(hds && std::atoi(hds) == 0) && nwg2 > 0;
+  // ... and with few enough intervals that their workgroups cannot keep the pass off the GPU, phase 2 follows the pass
+  // WHILE it runs, waiting for each chunk's ready flag
+  const char *pls = std::getenv("TEHMM_WIDE_POLL");
+  const bool poll = head && b->n <= 64 && !(pls && std::atoi(pls) == 0);
+  if (head) {
+    w.h_hstop.assign((size_t)b->n, 0);
+    for (int i = 0; i < b->n; ++i) {
+      int64_t hs = b->h_len[(size_t)i];
+      for (int64_t c = sw.h_first[i]; c < sw.h_first[i + 1]; ++c)
+        if (w.h_e[(size_t)c] != TEHMM_SPEC_NONE) { hs = sw.h_t0[(size_t)c]; break; }
+      w.h_hstop[(size_t)i] = hs;
+    }
+    HIPCHK(w.hstop.ensure((size_t)b->n + 1));
+    HIPCHK(w.hvec.ensure((size_t)b->n * m->NP + 1));
+    HIPCHK(w.hflag.ensure((size_t)b->n + 1));
+    HIPCHK(hipMemcpyAsync(w.hstop.p, w.h_hstop.data(), (size_t)b->n * sizeof(int64_t), hipMemcpyHostToDevice, st));
+  }
   HIPCHK(hipMemcpyAsync(sw.e.p, w.h_e.data(), (size_t)nc * sizeof(int), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemsetAsync(sw.ok.p, 0, (size_t)nc * sizeof(int), st));
   HIPCHK(hipMemsetAsync(sw.ntie.p, 0, (size_t)nc * sizeof(int), st));
   HIPCHK(hipMemsetAsync(sw.stats.p, 0, 8 * sizeof(int), st));
   HIPCHK(hipMemsetAsync(w.sel_hyp.p, 0xff, ((size_t)nc + 1) * sizeof(int), st));
+  HIPCHK(hipMemsetAsync(w.ready.p, 0, ((size_t)nc + 1) * sizeof(int), st));
+  const size_t ldsf = wide_lds_bytes(em.lds_rows, m->NP);
+  auto launch_chain = [&](int phase, hipStream_t s2) {
+    if (ratio) {
+      allow_lds(k_vit_wide_fix<true>, ldsf);
+      hipLaunchKernelGGL((k_vit_wide_fix<true>), dim3(b->n), dim3(256), ldsf, s2, iv, em, vc, m->N, m->NP, (const double *)m->lt.p,
+                         (const double *)m->pi.p, (const double *)b->ratios.p, b->TBW, b->tb.p, b->last_state.p, b->vit_lp.p,
+                         sw.stats.p, (const double *)w.rows2.p, (const double *)w.BL.p, w.sel_from.p, w.sel_hyp.p,
+                         (const double *)w.pre.p, phase, (const int64_t *)w.hstop.p, w.hvec.p, w.hflag.p,
+                         (const int *)(phase == 2 && poll ? w.ready.p : nullptr));
+    } else {
+      allow_lds(k_vit_wide_fix<false>, ldsf);
+      hipLaunchKernelGGL((k_vit_wide_fix<false>), dim3(b->n), dim3(256), ldsf, s2, iv, em, vc, m->N, m->NP, (const double *)m->lt.p,
+                         (const double *)m->pi.p, (const double *)nullptr, b->TBW, b->tb.p, b->last_state.p, b->vit_lp.p,
+                         sw.stats.p, (const double *)w.rows2.p, (const double *)w.BL.p, w.sel_from.p, w.sel_hyp.p,
+                         (const double *)w.pre.p, phase, (const int64_t *)w.hstop.p, w.hvec.p, w.hflag.p,
+                         (const int *)(phase == 2 && poll ? w.ready.p : nullptr));
+    }
+  };
+  if (head) {
+    (void)hipEventRecord(b->evX[0], st);
+    (void)hipStreamWaitEvent(b->sB, b->evX[0], 0);
+    launch_chain(1, b->sB);
+    if (!poll) (void)hipEventRecord(b->evX[1], b->sB);
+  }
   if (nwg2 > 0) {
     HIPCHK(w.wk_c.ensure(w.h_wkc.size() + 8));
     HIPCHK(w.wk_e.ensure(w.h_wke.size() + 8));
@@ -1719,31 +1830,30 @@ static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalT
       allow_lds(k_vit_wide_spec<true, true>, lds);
       hipLaunchKernelGGL((k_vit_wide_spec<true, true>), dim3(nwg2), dim3(512), lds, st, iv, vc, m->N, m->NP,
                          (const double *)m->lt.p, (const double *)w.BL.p, (const double *)b->ratios.p,
-                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, b->tb.p, w.tb2.p, w.rows2.p, wide_vit_warmup(CS), w.pre.p);
+                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, w.tb1.p, w.tb2.p, w.rows2.p, wide_vit_warmup(CS), w.pre.p,
+                         w.ready.p);
     } else {
       allow_lds(k_vit_wide_spec<true, false>, lds);
       hipLaunchKernelGGL((k_vit_wide_spec<true, false>), dim3(nwg2), dim3(512), lds, st, iv, vc, m->N, m->NP,
                          (const double *)m->lt.p, (const double *)w.BL.p, (const double *)nullptr,
-                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, b->tb.p, w.tb2.p, w.rows2.p, wide_vit_warmup(CS), w.pre.p);
+                         (const int *)w.wk_c.p, (const int *)w.wk_e.p, b->TBW, w.tb1.p, w.tb2.p, w.rows2.p, wide_vit_warmup(CS), w.pre.p,
+                         w.ready.p);
     }
   }
+  (void)hipEventRecord(ev_spec, st);                 // the throughput passes are behind: what follows is latency-bound
   // the exact chain
-  const size_t ldsf = wide_lds_bytes(em.lds_rows, m->NP);
-  if (ratio) {
-    allow_lds(k_vit_wide_fix<true>, ldsf);
-    hipLaunchKernelGGL((k_vit_wide_fix<true>), dim3(b->n), dim3(256), ldsf, st, iv, em, vc, m->N, m->NP, (const double *)m->lt.p,
-                       (const double *)m->pi.p, (const double *)b->ratios.p, b->TBW, b->tb.p, b->last_state.p, b->vit_lp.p,
-                       sw.stats.p, (const double *)w.rows2.p, (const double *)w.BL.p, w.sel_from.p, w.sel_hyp.p,
-                       (const double *)w.pre.p);
+  if (poll) {
+    launch_chain(2, b->sB);                          // behind the heads, next to the pass it follows
+    (void)hipEventRecord(b->evX[1], b->sB);
+    (void)hipStreamWaitEvent(st, b->evX[1], 0);
+  } else if (head) {
+    (void)hipStreamWaitEvent(st, b->evX[1], 0);
+    launch_chain(2, st);
   } else {
-    allow_lds(k_vit_wide_fix<false>, ldsf);
-    hipLaunchKernelGGL((k_vit_wide_fix<false>), dim3(b->n), dim3(256), ldsf, st, iv, em, vc, m->N, m->NP, (const double *)m->lt.p,
-                       (const double *)m->pi.p, (const double *)nullptr, b->TBW, b->tb.p, b->last_state.p, b->vit_lp.p,
-                       sw.stats.p, (const double *)w.rows2.p, (const double *)w.BL.p, w.sel_from.p, w.sel_hyp.p,
-                       (const double *)w.pre.p);
+    launch_chain(0, st);
   }
-  hipLaunchKernelGGL(k_wide_tb_select, dim3(nc), dim3(256), 0, st, iv, vc, m->N, b->TBW, b->tb.p, (const uint8_t *)w.tb2.p,
-                     (const int64_t *)w.sel_from.p, (const int *)w.sel_hyp.p);
+  hipLaunchKernelGGL(k_wide_tb_select, dim3(nc), dim3(256), 0, st, iv, vc, m->N, b->TBW, b->tb.p, (const uint8_t *)w.tb1.p,
+                     (const uint8_t *)w.tb2.p, (const int64_t *)w.sel_from.p, (const int *)w.sel_hyp.p);
   if (std::getenv("TEHMM_SPEC_DEBUG")) {
     HIPCHK(hipStreamSynchronize(st));
     std::vector<int> hok((size_t)nc), hnt((size_t)nc), hsel((size_t)nc);
@@ -2004,6 +2114,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   };
   bool wide_cp = false;                             // the chunk-parallel posterior for 64 <= N <= 128 ran
   bool wide_vit = false;                            // ... and the chunk-parallel exact Viterbi
+  bool wide_pending = false;                        // a chunk-parallel posterior attempt is in flight
   auto enqueue_posterior = [&]() -> int {
     hipStream_t st = b->sP;
     (void)hipEventRecord(b->ev[10], st);            // start of the passes (behind any deferral wait)
@@ -2072,14 +2183,29 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       hipLaunchKernelGGL(k_poison_dead, dim3(64, std::min(b->n, 1024)), dim3(256), 0, st, iv, b->dead.p, m->N, b->post.p,
                          b->fwd_lp.p);
     } else {
-      bool wide_done = false;
-      rc = posterior_wide_cp(b, m, iv, em, st, b->ev[eP + 1], &wide_done);
+      // 64 <= N <= 128: the chunk-parallel passes are enqueued; their verdict is read behind the Viterbi enqueue
+      // (finish_wide_posterior), so the two pipelines share the GPU
+      rc = posterior_wide_cp(b, m, iv, em, st, b->ev[eP + 1], &wide_pending);
       if (rc) return rc;
-      wide_cp = wide_done;
-      if (!wide_done) {
+      if (!wide_pending) {
         if (SPL == 1) launch_posterior<1>(b, m, iv, em, st, b->ev[eP + 1]);
         else launch_posterior<2>(b, m, iv, em, st, b->ev[eP + 1]);
       }
+    }
+    (void)hipEventRecord(b->ev[eP + 2], st);
+    return TEHMM_OK;
+  };
+  auto finish_wide_posterior = [&]() -> int {
+    if (!wide_pending) return TEHMM_OK;
+    wide_pending = false;
+    hipStream_t st = b->sP;
+    bool wide_done = false;
+    int rcw = posterior_wide_finish(b, m, iv, st, b->ev[eP + 1], &wide_done);
+    if (rcw) return rcw;
+    wide_cp = wide_done;
+    if (!wide_done) {
+      if (SPL == 1) launch_posterior<1>(b, m, iv, em, st, b->ev[eP + 1]);
+      else launch_posterior<2>(b, m, iv, em, st, b->ev[eP + 1]);
     }
     (void)hipEventRecord(b->ev[eP + 2], st);
     return TEHMM_OK;
@@ -2094,10 +2220,14 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
 #undef CALL
     if (rcp) return rcp;
   }
+  // 64 <= N <= 128 (tehmm_wide.hip.h), both results: the same order, arranged at the Viterbi enqueue below
+  const bool wide_defer = vit && postr && !vspec && !coop && m->N >= 64 && !(dfs && std::atoi(dfs) == 0);
   if (postr && !defer_post) {
     enqueue_emission();
-    rc = enqueue_posterior();
-    if (rc) return rc;
+    if (!wide_defer) {
+      rc = enqueue_posterior();
+      if (rc) return rc;
+    }
   }
   // item gains of a lane P0 pass -> chunk gains (chunks the lanes did not run: see below)
   auto chunk_gains = [&](std::vector<double> &cgain) {
@@ -2257,11 +2387,17 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
     } else {
-      rc = viterbi_wide_cp(b, m, iv, em, ratio, st, &wide_vit);
+      rc = viterbi_wide_cp(b, m, iv, em, ratio, st, b->ev[eV + 3], &wide_vit);
       if (rc) return rc;
       if (!wide_vit) {
         if (SPL == 1) launch_viterbi<1>(b, m, iv, em, ratio, st);
         else launch_viterbi<2>(b, m, iv, em, ratio, st);
+      }
+      if (wide_defer) {
+        // the posterior passes go behind the quantised Viterbi pass, next to the exact chain (few CUs, latency-bound)
+        if (wide_vit) (void)hipStreamWaitEvent(b->sP, b->ev[eV + 3], 0);
+        rc = enqueue_posterior();
+        if (rc) return rc;
       }
     }
     (void)hipEventRecord(b->ev[eV + 1], st);
@@ -2314,6 +2450,8 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     b->tnames.push_back("traceback");
     b->tpairs.push_back({eV + 1, eV + 2});
   }
+  rc = finish_wide_posterior();
+  if (rc) return rc;
   if (postr) {
     if (flane && fused_fb) {
       b->tnames.push_back("forward_pass");               // lane pass + links + exact forward chain

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks
                                                        const double *__restrict__ g_lt, const double *__restrict__ BL,
                                                        const double *__restrict__ tratios, const int *__restrict__ wk_c,
                                                        const int *__restrict__ wk_e, int TBW, uint8_t *tb, uint8_t *tb2,
-                                                       double *rows2, int WU, double *pre) {
+                                                       double *rows2, int WU, double *pre, int *ready = nullptr) {
   extern __shared__ double wsm[];
   double *tq = wsm;
   volatile int *tflag = (volatile int *)(wsm + (size_t)N * TEHMM_WIDE_S);
@@ -743,10 +743,110 @@ __global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks
       vc.ties[(int64_t)c * TEHMM_SPEC_MAXT] = first_tie;      // where the second set of traceback bytes starts
       vc.ok[c] = anybad ? 0 : 1;
     }
+    if (ready) {
+      // the exact chain may be waiting for this chunk (k_vit_wide_fix, `ready`): everything the wave wrote -- rows, pre,
+      // traceback bytes, ok -- is visible before the flag is
+      __threadfence();
+      if (lane == 0) __hip_atomic_store(&ready[c], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
   } else {
     const double g = wave_max_f64(fmax(live0 ? W0[0] : -INFINITY, live1 ? W1[0] : -INFINITY));
     if (lane == 0) vc.gain[c] = g;
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// P0 in packed floats: the gain of every chunk (max of the vector after the chunk, started from zeros) only places the
+// chunk in its binade -- spec_assign_binades keeps 512 + 2e-5 |score| of margin -- so single precision does, and the
+// lane's two states share one v_pk_add_f32 / v_pk_max_f32 per from-state.  The table sits in LDS as float2
+// [from][lane] = (to lane, to lane + 64): 51 KB at 100 states, two workgroups per CU.  Every 32 positions the vector
+// is re-based on its maximum (accumulated in fp64), so the floats stay below ~10^3.  One wave per chunk, ragged
+// tails included; a NaN row (nothing can emit) makes the gain NaN.
+// ------------------------------------------------------------------------------------------
+template <bool RATIO>
+__global__ __launch_bounds__(512) void k_vit_wide_gain(IntervalTab iv, VitChunks vc, int N, int NP,
+                                                       const double *__restrict__ g_lt, const double *__restrict__ BL,
+                                                       const double *__restrict__ tratios) {
+  extern __shared__ double wsm[];
+  float2 *tqf = (float2 *)wsm;
+  for (int i = threadIdx.x; i < N * 64; i += blockDim.x) {
+    const int f = i >> 6, j = i & 63;
+    tqf[i] = make_float2(j < N ? (float)g_lt[(size_t)f * NP + j] : -INFINITY,
+                         j + 64 < N ? (float)g_lt[(size_t)f * NP + j + 64] : -INFINITY);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 8 + w;
+  if (c >= vc.n) return;
+  const int id = vc.iv[c];
+  const int64_t p0 = iv.pos0[id], t0 = vc.t0[c];
+  const int len = (int)min((int64_t)vc.CS, iv.len[id] - t0);
+  const bool live0 = lane < N, live1 = lane + 64 < N;
+  lane_f2 W = (lane_f2){live0 ? 0.f : -INFINITY, live1 ? 0.f : -INFINITY};
+  const float ltd0 = live0 ? (float)g_lt[(size_t)lane * NP + lane] : 0.f;
+  const float ltd1 = live1 ? (float)g_lt[(size_t)(lane + 64) * NP + lane + 64] : 0.f;
+  const float lt00 = (float)g_lt[0];
+  const int n0 = min(N, 64);
+  const double *bp = BL + (p0 + t0) * TEHMM_WIDE_S;
+  double bn0 = bp[lane], bn1 = bp[lane + 64];
+  double acc = 0.0;
+  bool bad = false;
+  const lane_f2 *tp = (const lane_f2 *)tqf + lane;
+  for (int s = 0; s < len; ++s) {
+    const double b0 = bn0, b1 = bn1;
+    if (s + 1 < len) {
+      bn0 = bp[(int64_t)(s + 1) * TEHMM_WIDE_S + lane];
+      bn1 = bp[(int64_t)(s + 1) * TEHMM_WIDE_S + lane + 64];
+    }
+    bad = bad | (live0 && b0 != b0) | (live1 && b1 != b1);
+    lane_f2 add = (lane_f2){0.f, 0.f}, dz = (lane_f2){0.f, 0.f};
+    if (RATIO) {
+      // _hmm.pyx:201-259 with segment ratios: the candidate from state 0 gets lt[j][j] r, the others lt[j][j] (r - 1)
+      // when r > 1 (and state 0's own column loses lt[0][0]): see k_vit_wide_spec
+      const float r = (float)tratios[p0 + t0 + s];
+      const lane_f2 za = (lane_f2){ltd0, ltd1} * (lane_f2){r, r};
+      if (r > 1.f) add = (lane_f2){ltd0, ltd1} * (lane_f2){r - 1.f, r - 1.f};
+      dz = za - add;
+      if (lane == 0) dz.x -= lt00;
+    }
+    const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, W.x), 0));
+    lane_f2 x = (lane_f2){s0, s0} + tp[0] + dz;
+    auto oct = [&](const float wreg, int fb, int lb) {
+      lane_f2 ta[8];
+      float sv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ta[i] = tp[(fb + i) * 64];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sv[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wreg), lb + i));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x = __builtin_elementwise_max(x, (lane_f2){sv[i], sv[i]} + ta[i]);
+    };
+    int f = 1;
+    for (; f + 8 <= n0; f += 8) oct(W.x, f, f);
+    for (; f < n0; ++f) {
+      const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, W.x), f));
+      x = __builtin_elementwise_max(x, (lane_f2){sv, sv} + tp[f * 64]);
+    }
+    f = 64;
+    for (; f + 8 <= N; f += 8) oct(W.y, f, f - 64);
+    for (; f < N; ++f) {
+      const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, W.y), f - 64));
+      x = __builtin_elementwise_max(x, (lane_f2){sv, sv} + tp[f * 64]);
+    }
+    W = x + (lane_f2){(float)b0, (float)b1} + add;
+    if (!live0) W.x = -INFINITY;
+    if (!live1) W.y = -INFINITY;
+    if ((s & 31) == 31) {
+      const float mx = (float)wave_max_f64((double)fmaxf(W.x, W.y));
+      if (mx > -INFINITY) {
+        W = W - (lane_f2){mx, mx};
+        acc += (double)mx;
+      }
+    }
+  }
+  const double g = acc + wave_max_f64((double)fmaxf(W.x, W.y));
+  const bool anybad = __ballot(bad) != 0ull;
+  if (lane == 0) vc.gain[c] = anybad ? __longlong_as_double(0x7ff8000000000000LL) : g;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -763,8 +863,9 @@ template <bool RATIO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_vit_wide_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, int NP, const double *g_lt, const double *g_pi,
                     const double *tratios, int TBW, uint8_t *tb, int *last_state, double *logprob, int *stats,
-                    const double *__restrict__ rows2, const double *__restrict__ BL, int64_t *sel_from, int *sel_hyp,
-                    const double *__restrict__ pre) {
+                    const double *rows2, const double *__restrict__ BL, int64_t *sel_from, int *sel_hyp,
+                    const double *pre, int phase, const int64_t *__restrict__ hstop, double *hvec, int *hflag,
+                    const int *ready = nullptr) {
   extern __shared__ double sm[];
   constexpr int W = TEHMM_WIDE_W, QM = TEHMM_WIDE_QM;
   double *ring = sm;
@@ -801,6 +902,51 @@ void k_vit_wide_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, int NP, con
   int n_block = 0, n_jump = 0;
   double vfin[2] = {-INFINITY, -INFINITY};          // this lane's two states of the current vector
   int64_t t0 = 0, since = 0;                        // block start; where the exact run (re)started
+  // phase 1 = the interval's head only: positions [0, hstop) -- everything before its first speculated chunk, which no
+  // quantised pass helps with -- walked while that pass is still running (another stream); the vector at hstop - 1
+  // goes to hvec.  phase 2 resumes there.  phase 0: the whole interval in one launch.
+  // ready != nullptr: the quantised pass may still be RUNNING (it was launched before this kernel, on another stream,
+  // and sets ready[c] behind everything else it writes for chunk c).  Before the chain looks at a speculated chunk it
+  // waits for that flag: thread 0 polls, the workgroup meets at a barrier, every thread then fences (acquire, agent
+  // scope) so that no stale cache line answers for the chunk's rows.  The pass does not depend on the chain and the
+  // host launches this form only when the chain's workgroups cannot fill the GPU, so the wait always ends; the spin
+  // budget (about a second per interval) is a safety net behind which the chunk is simply walked exactly -- its quantised traceback bytes
+  // live in their own buffers (k_wide_tb_select), so a late writer cannot disturb the exact ones.
+  __shared__ int s_rdy;
+  int64_t lastready = -1;
+  int spin_budget = 1 << 19;         // (thread 0) polls left for the whole interval: ~1 s of waiting at most
+  auto wait_chunk = [&](int64_t c) -> bool {
+    if (!ready || lastready == c) return true;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int ok = 0;
+      for (;;) {
+        ok = __hip_atomic_load(&ready[c], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (ok || spin_budget <= 0) break;
+        --spin_budget;
+        __builtin_amdgcn_s_sleep(64);
+      }
+      s_rdy = ok;
+    }
+    __syncthreads();
+    const int ok = s_rdy;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (ok) lastready = c;
+    return ok != 0;
+  };
+  const int64_t hs = phase != 0 ? min(T, hstop[id]) : 0;
+  const int64_t Tend = phase == 1 ? hs : T;
+  if (phase == 2 && hs > 0 && hflag[id] != 0) {
+    double *vj = vmine + cur * W;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int j = lane + 64 * s;
+      vfin[s] = j < N ? hvec[(size_t)id * NP + j] : -INFINITY;
+      vj[j] = vfin[s];
+    }
+    seen = true;
+    t0 = since = hs;
+  }
   double bnx[2] = {0.0, 0.0};                       // log row of position tnx, requested a step ahead
   int64_t tnx = -1;
   // Does the current vector (vfin, position `at`) equal a recorded row of chunk c's quantised pass up to ONE constant
@@ -872,14 +1018,14 @@ void k_vit_wide_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, int NP, con
     ++n_jump;
     return true;
   };
-  while (t0 < T) {
+  while (t0 < Tend) {
     // ---- at a chunk's first position: the quantised pass warmed up before the chunk, its vector at t0 - 1 (`pre`)
     // can be compared with the chain's right away -- a verified chunk costs the chain no step at all
-    {
+    if (phase != 1) {
       const int64_t c = cfirst + t0 / CS;
       const int64_t ct0 = vc.t0[c];
       const int e = vc.e[c];
-      if (t0 == ct0 && t0 > 0 && e != TEHMM_SPEC_NONE && vc.ok[c] != 0 && seen) {
+      if (t0 == ct0 && t0 > 0 && e != TEHMM_SPEC_NONE && seen && wait_chunk(c) && vc.ok[c] != 0) {
         double wrow[2][2], wend[2][2];
         const int64_t eo = ((c * (CS / TEHMM_VROW)) + (CS / TEHMM_VROW - 1)) * NP;
 #pragma unroll
@@ -898,7 +1044,7 @@ void k_vit_wide_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, int NP, con
       }
     }
     ++n_block;
-    const int np = (int)min((int64_t)TEHMM_PB, T - t0);
+    const int np = (int)min((int64_t)TEHMM_PB, Tend - t0);
     const bool use_ring = !seen;                    // (uniform: every wave walks the leading rows alike)
     if (use_ring) {
       wide_emission_block<0, false>(em, p0 + t0, t0, np, lane, w, N, ltd, nullptr, seen, fg, ring, nullptr, ltab);
@@ -911,7 +1057,7 @@ void k_vit_wide_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, int NP, con
     const int64_t c = cfirst + t0 / CS;
     const int64_t ct0 = vc.t0[c];
     const int e = vc.e[c];
-    const bool spec = e != TEHMM_SPEC_NONE && np == TEHMM_PB && vc.ok[c] != 0 && seen;
+    const bool spec = phase != 1 && e != TEHMM_SPEC_NONE && np == TEHMM_PB && seen && wait_chunk(c) && vc.ok[c] != 0;
     const int64_t g = t0 + (TEHMM_VROW - 1 - ((t0 - ct0) & (TEHMM_VROW - 1)));
     const int64_t target = ct0 + CS;
     const bool do_check = spec && g < t0 + np && g + 1 < target && g >= since + TEHMM_FIX_MINSTEP;
@@ -1026,6 +1172,18 @@ void k_vit_wide_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, int NP, con
     if (!jumped) t0 += np;
     __syncthreads();
   }
+  if (phase == 1) {
+    if (w == 0) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        if (lane + 64 * s < NP) hvec[(size_t)id * NP + lane + 64 * s] = vfin[s];
+    }
+    if (threadIdx.x == 0) {
+      hflag[id] = (seen && hs > 0) ? 1 : 0;
+      if (stats) atomicAdd(&stats[0], n_block);
+    }
+    return;
+  }
   // np.argmax over V[T-1] (first maximum; a NaN wins as soon as it is met)
   if (threadIdx.x == 0) {
     const double *v = vmine + cur * W;
@@ -1044,18 +1202,26 @@ void k_vit_wide_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, int NP, con
   }
 }
 
-// the second set of traceback bytes where the chain adopted hypothesis 1: one workgroup per chunk
+// Traceback bytes of the adopted chunks: the quantised pass keeps them in its own two buffers (hypothesis 0 for the
+// whole chunk, hypothesis 1 from the chunk's first tie on -- before it the hypotheses agree), the chain says which
+// hypothesis it took and from where; the exact chain's own bytes, written straight to tb, are never touched by a
+// pass that is still running.  One workgroup per chunk.
 __global__ __launch_bounds__(256) void k_wide_tb_select(IntervalTab iv, VitChunks vc, int N, int TBW, uint8_t *tb,
-                                                        const uint8_t *__restrict__ tb2, const int64_t *sel_from,
-                                                        const int *sel_hyp) {
+                                                        const uint8_t *__restrict__ tb1, const uint8_t *__restrict__ tb2,
+                                                        const int64_t *sel_from, const int *sel_hyp) {
   const int c = blockIdx.x;
-  if (sel_hyp[c] != 1) return;
+  const int hyp = sel_hyp[c];
+  if (hyp < 0) return;
   const int id = vc.iv[c];
   const int64_t p0 = iv.pos0[id], ct0 = vc.t0[c];
-  const int64_t from = max(sel_from[c], ct0 + (int64_t)vc.ties[(int64_t)c * TEHMM_SPEC_MAXT]);
-  const int64_t n = (ct0 + vc.CS - from) * (int64_t)TBW;
+  const int64_t from = sel_from[c], end = ct0 + vc.CS;
+  const int64_t split = hyp == 1 ? min(end, max(from, ct0 + (int64_t)vc.ties[(int64_t)c * TEHMM_SPEC_MAXT])) : end;
   const int64_t o = (p0 + from) * (int64_t)TBW;
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) tb[o + i] = tb2[o + i];
+  const int64_t n1 = (split - from) * (int64_t)TBW, n = (end - from) * (int64_t)TBW;
+  // (TBW is a multiple of 4: dwords)
+  const uint32_t *s1 = (const uint32_t *)(tb1 + o), *s2 = (const uint32_t *)(tb2 + o);
+  uint32_t *d = (uint32_t *)(tb + o);
+  for (int64_t i = threadIdx.x; i < n / 4; i += blockDim.x) d[i] = i < n1 / 4 ? s1[i] : s2[i];
 }
 
 }  // namespace tehmm
