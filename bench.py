@@ -475,12 +475,12 @@ def extras(args, model, hm, hb, obs, offs, lens, device, torch, mk_model):
     hb5 = HipBatch(ob.data_ptr(), o5, ratios=r5.data_ptr(), device_ptrs=True, K=K)
     d = time_eval(hm5, hb5, torch, viterbi=True, posterior=True, use_ratios=True)
     ex["config5_100_states_segmented"] = rate(int(o5[-1]), d, positions=int(o5[-1]), kernel_ms=hb5.timing())
-    # the two halves: the posterior runs item-parallel on the matrix cores (tehmm_wide.hip.h), the exact Viterbi with
-    # segment ratios is still ONE four-wave workgroup per interval at this state count
+    # the two halves: the posterior runs item-parallel on the matrix cores, the exact Viterbi with segment ratios
+    # chunk-parallel with an exact chain that follows the quantised pass (tehmm_wide.hip.h)
     d = time_eval(hm5, hb5, torch, viterbi=False, posterior=True, use_ratios=True)
     ex["config5_100_states_posterior_only"] = rate(int(o5[-1]), d, positions=int(o5[-1]), kernel_ms=hb5.timing())
     d = time_eval(hm5, hb5, torch, viterbi=True, posterior=False, use_ratios=True)
-    ex["config5_100_states_viterbi_only"] = rate(int(o5[-1]), d, positions=int(o5[-1]))
+    ex["config5_100_states_viterbi_only"] = rate(int(o5[-1]), d, positions=int(o5[-1]), kernel_ms=hb5.timing())
     hb5.close()
     hm5.close()
     del ob, r5

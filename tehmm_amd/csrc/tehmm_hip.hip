@@ -1677,7 +1677,9 @@ static int posterior_wide_cp(tehmm_batch *b, const tehmm_model *m, const Interva
 // false: the caller runs the sequential kernels
 static int wide_vit_warmup(int CS) {    // positions the quantised pass runs ahead of its chunk (<= chunk length)
   const char *s = std::getenv("TEHMM_WIDE_VIT_WARMUP");
-  return std::min(CS, std::max(0, s ? std::atoi(s) : 64));
+  // (measured at 100 states, exact blocks of the chain per 480 kb: dense 3 300 at 64 and at 32 positions; sticky 0.995:
+  //  1 397 at 64, 1 392 at 32, 1 728 at 16 -- a chunk that has not converged only costs the chain one 16-position block)
+  return std::min(CS, std::max(0, s ? std::atoi(s) : 32));
 }
 static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em, bool ratio,
                            hipStream_t st, hipEvent_t ev_spec, bool *done) {

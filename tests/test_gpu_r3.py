@@ -475,3 +475,60 @@ def test_wide_viterbi_chunk_parallel_bit_exact(monkeypatch, N, with_ratio, kw):
         for mode in ("1", "0"):
             assert_array_equal(got[mode][1][a:b], path_o)
             assert got[mode][0][i] == lp_o
+
+
+@pytest.mark.timeout(900)
+def test_wide_viterbi_chain_forms_agree(monkeypatch):
+    """The exact chain of the 64..128-state Viterbi in its three forms -- following the quantised pass chunk by chunk
+    (ready flags, the default for few intervals), behind the pass with the interval heads walked beside it
+    (TEHMM_WIDE_POLL=0), and in one launch (TEHMM_WIDE_HEAD=0) -- and both results requested at once (the posterior
+    passes then share the GPU with the chain): identical paths and scores, equal to the oracle's; posteriors of the
+    combined evaluation equal to those of a posterior-only one."""
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    from oracle import oracle
+    for k in ("TEHMM_WIDE_VIT", "TEHMM_WIDE_CP", "TEHMM_SPEC_CHUNK", "TEHMM_WIDE_POLL", "TEHMM_WIDE_HEAD", "TEHMM_DEFER"):
+        monkeypatch.delenv(k, raising=False)
+    N = 100
+    model = synth.make_model(N, synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=11)
+    rs = np.random.RandomState(4)
+    lens = [52000, 38000, 47000, 700, 9000]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    T = int(offs[-1])
+    obs = synth.sample_obs(model, T, seed=9, missing=0.02)
+    ratios = synth.random_ratios(T, seed=2)
+    ratios[rs.rand(T) < 0.4] = 1.0
+    ratios = np.ascontiguousarray(ratios)
+    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, 1.0, model.symbols_per_track)
+    got = {}
+    for tag, env in (("follow", {}), ("behind", {"TEHMM_WIDE_POLL": "0"}), ("one_launch", {"TEHMM_WIDE_HEAD": "0"})):
+        for k in ("TEHMM_WIDE_POLL", "TEHMM_WIDE_HEAD"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        hb = HipBatch(obs, offs, ratios)
+        res = hm.eval(hb, viterbi=True, posterior=False, use_ratios=True)
+        tm = hb.timing()
+        assert tm.get("count:viterbi_chunk_jumps", 0) > 0
+        got[tag] = (res["viterbi_logprob"].copy(), np.array(hb.paths()))
+        hb.close()
+    for k in ("TEHMM_WIDE_POLL", "TEHMM_WIDE_HEAD"):
+        monkeypatch.delenv(k, raising=False)
+    hb = HipBatch(obs, offs, ratios)
+    res = hm.eval(hb, viterbi=True, posterior=True, use_ratios=True)
+    tm = hb.timing()
+    assert tm.get("count:viterbi_chunk_jumps", 0) > 0 and tm.get("count:wide_chunk_parallel_warmup", 0) > 0
+    got["both"] = (res["viterbi_logprob"].copy(), np.array(hb.paths()))
+    post_both, flp_both = np.array(hb.posteriors()), res["forward_logprob"].copy()
+    res = hm.eval(hb, viterbi=False, posterior=True, use_ratios=True)
+    assert_array_equal(np.array(hb.posteriors()), post_both)
+    assert_array_equal(res["forward_logprob"], flp_both)
+    hb.close()
+    for tag in ("behind", "one_launch", "both"):
+        assert_array_equal(got[tag][1], got["follow"][1])
+        assert_array_equal(got[tag][0], got["follow"][0])
+    for i in (1, 3):
+        a, b = int(offs[i]), int(offs[i + 1])
+        lp_o, path_o = oracle.decode(obs[a:b], model.log_probs, model.log_startprob, model.log_transmat, 1.0, ratios[a:b])
+        assert_array_equal(got["follow"][1][a:b], path_o)
+        assert got["follow"][0][i] == lp_o
