@@ -1,3 +1,7 @@
+#!/bin/bash
+# Shape fuzz of the 64..128-state exact Viterbi against the oracle (tools/wide_vit_check.py): state counts, interval counts
+# on both sides of the polling limit (64), tiny intervals, sticky / sparse models, other chunk sizes.  Run on the GPU box:
+#   bash tools/wide_fuzz.sh      (every line must report 1 = ALL EXACT)
 set -o pipefail
 cd $GRAFT_REPO_ROOT
 i=0
