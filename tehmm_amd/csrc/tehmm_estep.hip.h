@@ -30,6 +30,7 @@
 // ~1e-7 (bar 1e-6, asserted in tests/test_gpu_r3.py).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "tehmm_fused.hip.h"
 
 namespace tehmm {
@@ -60,7 +61,7 @@ struct EstepGeom {
   static constexpr int PQ = (P + 3) / 4;                 // pair quads
   // state tiles (q, h): states 8 (4 q + pp) + 4 h + kq; a tile exists when its first state does
   static constexpr int NTILE = 2 * PQ - ((32 * (PQ - 1) + 4 < NT) ? 0 : 1);
-  static constexpr int RTG = 24 / NTILE;                 // row tiles per workgroup role of the one-hot reduction (96 accumulator doubles)
+  static constexpr int RTG = 8;                          // row tiles per workgroup of the one-hot reduction (<= 2 per wave)
   static __host__ __device__ constexpr int state(int tile, int m) {
     return 8 * (4 * (tile >> 1) + (m >> 2)) + 4 * (tile & 1) + (m & 3);
   }
@@ -135,10 +136,11 @@ __global__ __launch_bounds__(256) void k_estep_xi(IntervalTab iv, LaneGeom lg, i
       for (int q = 0; q < PQ; ++q)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-          const bool have = 4 * q + g_pp < P;
-          const int64_t ix = gb2 + (int64_t)s * (256 * P) + (4 * q + g_pp) * 64 + 4 * kk;
-          xa[q][kk] = have ? al2[ix] : make_float2(0.f, 0.f);
-          xw[q][kk] = have ? wz2[ix] : make_float2(0.f, 0.f);
+          // (unconditional loads from a clamped pair: a predicated load costs an exec-mask region and a branch, a select
+          //  right behind the load a wait for it)
+          const int64_t ix = gb2 + (int64_t)s * (256 * P) + min(4 * q + g_pp, P - 1) * 64 + 4 * kk;
+          xa[q][kk] = al2[ix];                      // (raw: a pair beyond the last one is dropped when consumed)
+          xw[q][kk] = wz2[ix];
         }
     };
     request(0);
@@ -148,8 +150,9 @@ __global__ __launch_bounds__(256) void k_estep_xi(IntervalTab iv, LaneGeom lg, i
       for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
         for (int t = 0; t < NTILE; ++t) {
-          a[kk][t] = (double)((t & 1) ? xa[t >> 1][kk].y : xa[t >> 1][kk].x);
-          w[kk][t] = (double)((t & 1) ? xw[t >> 1][kk].y : xw[t >> 1][kk].x);
+          const bool have = 4 * (t >> 1) + g_pp < P;
+          a[kk][t] = have ? (double)((t & 1) ? xa[t >> 1][kk].y : xa[t >> 1][kk].x) : 0.0;
+          w[kk][t] = have ? (double)((t & 1) ? xw[t >> 1][kk].y : xw[t >> 1][kk].x) : 0.0;
         }
       if (s + 1 < tc.nsmax) request(s + 1);          // (positions beyond an item's end hold zeros: never written)
 #pragma unroll
@@ -188,7 +191,7 @@ __device__ __forceinline__ void estep_hist_mfma_run(const IntervalTab &iv, const
                                                     const float *__restrict__ gam32, double *gstat, int rt0) {
   using G = EstepGeom<NT>;
   constexpr int P = G::P, PQ = G::PQ, NTILE = G::NTILE;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
   const int i16 = lane & 15;
   const int g_pp = (lane & 15) >> 2, g_kq = lane & 3, g_k = lane >> 4;
   // this lane's row of every row tile: observation column and symbol (padding rows: a symbol no observation
@@ -205,9 +208,31 @@ __device__ __forceinline__ void estep_hist_mfma_run(const IntervalTab &iv, const
   for (int a = 0; a < RT; ++a)
 #pragma unroll
     for (int b = 0; b < NTILE; ++b) acc[a][b] = (lane_d4){0.0, 0.0, 0.0, 0.0};
+#ifndef TEHMM_ESTEP_HIST_F64
+  // The products are exact in single precision (1.0 x a float gamma) and v_mfma_f32_16x16x4 issues twice as fast
+  // as the fp64 form (13.5 against 28 ns per SIMD, profiles/r03_peak_rates.txt): the matrix cores sum eight steps
+  // (<= 128 terms <= 1 per cell) in floats, then the partial sums go to the fp64 accumulators -- a relative 1e-7 per
+  // partial sum at worst, averaged over thousands of them per cell (the rows themselves are floats, 6e-8 each).
+  typedef float estep_f4 __attribute__((ext_vector_type(4)));
+  estep_f4 acc32[RT][NTILE];
+#pragma unroll
+  for (int a = 0; a < RT; ++a)
+#pragma unroll
+    for (int b = 0; b < NTILE; ++b) acc32[a][b] = (estep_f4){0.f, 0.f, 0.f, 0.f};
+  auto flush32 = [&]() {
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+      for (int b = 0; b < NTILE; ++b) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[a][b][q] += (double)acc32[a][b][q];
+        acc32[a][b] = (estep_f4){0.f, 0.f, 0.f, 0.f};
+      }
+  };
+#endif
   const int64_t n_tiles = (int64_t)lg.n_groups * 4;
   const float2 *gam2 = (const float2 *)gam32;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wv; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const EstepTile tc = estep_tile<NT>(iv, lg, tile, i16, KP, obs);
     if (tc.nsmax <= 0) continue;
     // the four items this lane contracts over (item 4 kk + g_k of the tile): observation rows and lengths
@@ -223,33 +248,47 @@ __device__ __forceinline__ void estep_hist_mfma_run(const IntervalTab &iv, const
       oo[kk] = (int64_t)(((unsigned long long)hi << 32) | lo);
     }
     const int64_t gb2 = tc.tb2 + g_kq * 16 + g_k;
-    float2 xg[PQ][4];
-    int sy[RT][4];                                                  // symbols of the step being requested
-    auto request = [&](int s) {
+    // Two steps are on their way at any time (buffers 0 / 1): the wave is alone on its SIMD (its accumulators take
+    // the register file), so nothing else hides the latency of the gamma rows and observation bytes -- with ONE step
+    // in flight a tile step took 4.8 us for 1.1 us of matrix instructions
+    float2 xg[2][PQ][4];
+    int sy[2][RT][4];
+    auto request = [&](int s, auto bsel) {
+      constexpr int B = decltype(bsel)::value;
+      // Every load is UNCONDITIONAL, from a clamped address inside the tile's own rows, and a select drops what lies
+      // beyond the item's end (a predicated load compiles to an exec-mask region with a branch: 36 of them per step
+      // were what this kernel spent its time on -- 4.8 us per tile step whatever the matrix instructions cost)
 #pragma unroll
       for (int q = 0; q < PQ; ++q)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-          const bool have = 4 * q + g_pp < P && s < nsk[kk];
-          xg[q][kk] = have ? gam2[gb2 + (int64_t)s * (256 * P) + (4 * q + g_pp) * 64 + 4 * kk] : make_float2(0.f, 0.f);
+          const int pc = min(4 * q + g_pp, P - 1);
+          xg[B][q][kk] = gam2[gb2 + (int64_t)s * (256 * P) + pc * 64 + 4 * kk];      // (raw: selected when consumed)
         }
 #pragma unroll
       for (int r = 0; r < RT; ++r)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-          sy[r][kk] = s < nsk[kk] ? (int)obs[oo[kk] + (int64_t)s * KP + rcol[r]] : 0xff;
+        for (int kk = 0; kk < 4; ++kk) {
+          const int sc = max(0, min(s, nsk[kk] - 1));
+          sy[B][r][kk] = (int)obs[oo[kk] + (int64_t)sc * KP + rcol[r]];
+        }
     };
-    request(0);
-    for (int s = 0; s < tc.nsmax; ++s) {
+    auto step = [&](int s, auto bsel) {
+      constexpr int B = decltype(bsel)::value;
+#ifdef TEHMM_ESTEP_HIST_F64
       double a[4][RT], w[4][NTILE];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
+        const bool live = s < nsk[kk];
 #pragma unroll
-        for (int r = 0; r < RT; ++r) a[kk][r] = __hiloint2double(sy[r][kk] == rsym[r] ? 0x3ff00000 : 0, 0);
+        for (int r = 0; r < RT; ++r) a[kk][r] = __hiloint2double((live && sy[B][r][kk] == rsym[r]) ? 0x3ff00000 : 0, 0);
 #pragma unroll
-        for (int t = 0; t < NTILE; ++t) w[kk][t] = (double)((t & 1) ? xg[t >> 1][kk].y : xg[t >> 1][kk].x);
+        for (int t = 0; t < NTILE; ++t) {
+          const bool have = live && 4 * (t >> 1) + g_pp < P;
+          w[kk][t] = have ? (double)((t & 1) ? xg[B][t >> 1][kk].y : xg[B][t >> 1][kk].x) : 0.0;
+        }
       }
-      if (s + 1 < tc.nsmax) request(s + 1);
+      if (s + 2 < tc.nsmax) request(s + 2, bsel);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -257,14 +296,54 @@ __device__ __forceinline__ void estep_hist_mfma_run(const IntervalTab &iv, const
 #pragma unroll
           for (int tw = 0; tw < NTILE; ++tw)
             acc[r][tw] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk][r], w[kk][tw], acc[r][tw], 0, 0, 0);
+#else
+      float a[4][RT], w[4][NTILE];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const bool live = s < nsk[kk];                   // beyond the item's end: no row matches, gamma counts as zero
+#pragma unroll
+        for (int r = 0; r < RT; ++r) a[kk][r] = (live && sy[B][r][kk] == rsym[r]) ? 1.f : 0.f;
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) {
+          const bool have = live && 4 * (t >> 1) + g_pp < P;
+          const float v = (t & 1) ? xg[B][t >> 1][kk].y : xg[B][t >> 1][kk].x;
+          w[kk][t] = have ? v : 0.f;
+        }
+      }
+      if (s + 2 < tc.nsmax) request(s + 2, bsel);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+          for (int tw = 0; tw < NTILE; ++tw)
+            acc32[r][tw] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk][r], w[kk][tw], acc32[r][tw], 0, 0, 0);
+      if ((s & 7) == 7) flush32();
+#endif
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    request(0, B0{});
+    if (tc.nsmax > 1) request(1, B1{});
+    for (int s = 0; s < tc.nsmax; s += 2) {
+      step(s, B0{});
+      if (s + 1 < tc.nsmax) step(s + 1, B1{});
     }
+#ifndef TEHMM_ESTEP_HIST_F64
+    flush32();
+#endif
   }
-  // accumulator (lane, register q) of (row tile r, state tile tw): row 4 q + (lane >> 4), state(tw, lane & 15)
+  // accumulator (lane, register q) of (row tile r, state tile tw): state(tw, lane & 15) and row 4 q + (lane >> 4)
+  // for the fp64 instruction, 4 (lane >> 4) + q for the fp32 one (tools/mfma_layout.hip)
 #pragma unroll
   for (int r = 0; r < RT; ++r) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+#ifdef TEHMM_ESTEP_HIST_F64
       const int row = (rt0 + r) * 16 + 4 * q + (lane >> 4);
+#else
+      const int row = (rt0 + r) * 16 + 4 * (lane >> 4) + q;
+#endif
       const int grow = egp->rt_info[row] < 0 ? -1 : egp->rt_grow[row];
 #pragma unroll
       for (int tw = 0; tw < NTILE; ++tw) {
@@ -276,17 +355,27 @@ __device__ __forceinline__ void estep_hist_mfma_run(const IntervalTab &iv, const
   }
 }
 
+#ifndef TEHMM_ESTEP_HW
+#define TEHMM_ESTEP_HW 4            // waves per workgroup of k_estep_hist_mfma
+#endif
+// The waves of a workgroup take the SAME tile and split the group's row tiles among them (<= 2 each): a wave
+// then holds 24 accumulator registers per row tile instead of the whole group's 96 doubles, three workgroups fit a CU
+// and one wave's matrix instructions run under another's loads and operand building (with all row tiles in one wave --
+// one wave per SIMD -- a tile step took 4.8 us for 1.1 us of matrix instructions).  The gamma rows are read by all
+// four (L1 / L2 hits after the first).
 template <int NT>
-__global__ __launch_bounds__(256) void k_estep_hist_mfma(IntervalTab iv, LaneGeom lg, const EstepGroups *__restrict__ egp,
-                                                         int N, int KP, const uint8_t *__restrict__ obs,
-                                                         const float *__restrict__ gam32, double *gstat) {
+__global__ __launch_bounds__(TEHMM_ESTEP_HW * 64) void k_estep_hist_mfma(IntervalTab iv, LaneGeom lg, const EstepGroups *__restrict__ egp,
+                                                                       int N, int KP, const uint8_t *__restrict__ obs,
+                                                                       const float *__restrict__ gam32, double *gstat) {
   constexpr int RTG = EstepGeom<NT>::RTG;
-  const int rt0 = blockIdx.y * RTG;
-  const int nrt = min(RTG, egp->n_rt - rt0);
-#define TEHMM_RUN(RT_)                                                                                       \
-  if (RT_ <= RTG && nrt == RT_) { estep_hist_mfma_run<NT, (RT_ <= RTG ? RT_ : 1)>(iv, lg, egp, N, KP, obs, gam32, gstat, rt0); return; }
-  TEHMM_RUN(8) TEHMM_RUN(7) TEHMM_RUN(6) TEHMM_RUN(5) TEHMM_RUN(4) TEHMM_RUN(3) TEHMM_RUN(2) TEHMM_RUN(1)
-#undef TEHMM_RUN
+  const int rtg0 = blockIdx.y * RTG;
+  const int nrt = min(RTG, egp->n_rt - rtg0);
+  const int rtw = (nrt + TEHMM_ESTEP_HW - 1) / TEHMM_ESTEP_HW;      // row tiles per wave
+  const int wv = threadIdx.x >> 6;
+  const int rt0 = rtg0 + wv * rtw;
+  const int mine = max(0, min(rtw, nrt - wv * rtw));
+  if (mine == 2) estep_hist_mfma_run<NT, 2>(iv, lg, egp, N, KP, obs, gam32, gstat, rt0);
+  else if (mine == 1) estep_hist_mfma_run<NT, 1>(iv, lg, egp, N, KP, obs, gam32, gstat, rt0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -319,12 +408,12 @@ __global__ __launch_bounds__(512) void k_estep_hist_lds(IntervalTab iv, LaneGeom
     float2 gn[P];
     uint32_t on[4];
     auto request = [&](int s) {
-      const bool ok = s < tc.ns;
+      const int sc = max(0, min(s, tc.ns - 1));             // unconditional loads from inside the item
 #pragma unroll
-      for (int p = 0; p < P; ++p) gn[p] = ok ? gam2[hb2 + (int64_t)s * (256 * P) + p * 64] : make_float2(0.f, 0.f);
-      const uint32_t *ow = (const uint32_t *)(tc.orow + (int64_t)s * KP);
+      for (int p = 0; p < P; ++p) gn[p] = gam2[hb2 + (int64_t)sc * (256 * P) + p * 64];      // (raw: used only when live)
+      const uint32_t *ow = (const uint32_t *)(tc.orow + (int64_t)sc * KP);
 #pragma unroll
-      for (int d = 0; d < 4; ++d) on[d] = (ok && 4 * d < KP) ? ow[d] : 0u;
+      for (int d = 0; d < 4; ++d) on[d] = ow[min(d, (KP >> 2) - 1)];
     };
     request(0);
     for (int s = 0; s < tc.nsmax; ++s) {

@@ -3040,7 +3040,8 @@ static void launch_estep_reduce(tehmm_batch *b, const tehmm_model *m, const Inte
   if (eg.n_rt > 0) {
     constexpr int RTG = EstepGeom<NT>::RTG;
     (void)hipStreamWaitEvent(b->sB, b->evX[0], 0);
-    hipLaunchKernelGGL((k_estep_hist_mfma<NT>), dim3(gxm, (eg.n_rt + RTG - 1) / RTG), dim3(256), 0, b->sB, iv, lg,
+    const int gxh = (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles, 768));     // one tile per workgroup at a time, 3 per CU
+    hipLaunchKernelGGL((k_estep_hist_mfma<NT>), dim3(gxh, (eg.n_rt + RTG - 1) / RTG), dim3(TEHMM_ESTEP_HW * 64), 0, b->sB, iv, lg,
                        (const EstepGroups *)w.d_groups.p, m->N, b->KP, (const uint8_t *)b->obs.p,
                        (const float *)lw.GAM32.p, gstat);
     (void)hipEventRecord(b->evX[1], b->sB);

@@ -17,8 +17,12 @@ def main():
     from tehmm_amd import synth
     from tehmm_amd.engine import HipBatch, HipModel
     mb = float(sys.argv[1]) if len(sys.argv) > 1 else 100.0
-    syms = (2, 2, 3, 4, 5, 8, 12, 30, 6, 10, 250, 250)
-    model = synth.make_model(35, syms, (10, 11), seed=0)
+    syms, gauss = (2, 2, 3, 4, 5, 8, 12, 30, 6, 10, 250, 250), (10, 11)
+    if os.environ.get("TRACKS"):              # e.g. TRACKS=2,2,3,4,5,8,12,30,6,10  (g suffix = gaussian bins)
+        ent = os.environ["TRACKS"].split(",")
+        syms = tuple(int(e.rstrip("g")) for e in ent)
+        gauss = tuple(i for i, e in enumerate(ent) if e.endswith("g"))
+    model = synth.make_model(35, syms, gauss, seed=0)
     total = int(mb * 1e6)
     lens = np.full(total // 100000, 100000, dtype=np.int64)
     offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
