@@ -1627,6 +1627,12 @@ static int posterior_wide_cp(tehmm_batch *b, const tehmm_model *m, const Interva
   int L = (int)std::min<int64_t>(512, std::max<int64_t>(64, (b->total / (16 * 1024) + 31) & ~31));
   if (const char *ls = std::getenv("TEHMM_WIDE_SUB")) L = std::max(32, (std::atoi(ls) + 31) & ~31);
   if (w.L != L || w.NPW != NPW || !w.item_iv.p) {
+    {
+      // emission rows (8 NPW bytes per position) + float alpha' rows (4 NPW): the sequential kernels need neither
+      size_t free_b = 0, total_b = 0;
+      HIPCHK(hipMemGetInfo(&free_b, &total_b));
+      if ((double)b->total * NPW * 12.5 + (double)(b->total / L + b->n + 64) * NPW * 40.0 > 0.9 * (double)free_b) return TEHMM_OK;
+    }
     std::vector<int> h_iv;
     std::vector<int64_t> h_t0, h_first((size_t)b->n + 1, 0);
     for (int i = 0; i < b->n; ++i) {
@@ -1698,6 +1704,15 @@ static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalT
   WideWork &w = b->ww;
   const int nc = sw.n_chunks;
   if (nc <= 0) return TEHMM_OK;
+  if (!w.BL.p) {
+    // workspaces: log rows (1 KB per position), two sets of traceback bytes, recorded rows -- if they do not fit next
+    // to what the batch holds already, the sequential kernels (which need none of it) take the call
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const double need = (double)b->total_pad * (TEHMM_WIDE_S * 8.0 + 2.0 * b->TBW) * 1.25 +
+                        (double)nc * ((sw.CS / TEHMM_VROW) + 2.0) * m->NP * 8.0 * 1.25;
+    if (need > 0.9 * (double)free_b) return TEHMM_OK;
+  }
   HIPCHK(w.BL.ensure((size_t)b->total_pad * TEHMM_WIDE_S + TEHMM_WIDE_S));
   HIPCHK(w.rows2.ensure((size_t)nc * (CS / TEHMM_VROW) * m->NP + 1));
   HIPCHK(w.pre.ensure((size_t)2 * nc * m->NP + 1));
