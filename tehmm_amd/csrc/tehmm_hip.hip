@@ -1395,7 +1395,9 @@ static int fused_prepare(tehmm_batch *b, const tehmm_model *m, const IntervalTab
 template <int NT>
 static int launch_fused_fb(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em_in,
                            const FbChunks &fc, int Wu, hipStream_t st, hipEvent_t ev_fwd, hipEvent_t ev_mid,
-                           bool estep = false) {
+                           bool estep = false, int half = 0, hipEvent_t ev_fwdk = nullptr) {
+  // half: 0 = the whole pipeline; 1 = the forward half only (pass, links, exact forward chain; ev_fwdk is recorded right
+  // behind the pass itself), 2 = the backward half only -- tehmm_eval_batch puts the quantised Viterbi pass between them
   LaneWork &lw = b->lw;
   const LaneGeom lg = lane_geom(lw);
   const dim3 gridm((unsigned)lw.n_groups);           // 4 tiles of 16 items per 256-thread block = one group
@@ -1426,8 +1428,10 @@ static int launch_fused_fb(tehmm_batch *b, const tehmm_model *m, const IntervalT
   do {                                                                                                              \
     allow_lds(k_fused_fwd<NT, LOG_>, lds_f);                                                                         \
     allow_lds(k_fused_bwd<NT, LOG_, true>, lds_b);                                                                   \
+    if (half != 2) {                                                                                                \
     hipLaunchKernelGGL((k_fused_fwd<NT, LOG_>), gridm, dim3(256), lds_f, st, iv, ft, lg, m->N, fc.CS, Wu,            \
                        (const double *)m->A.p, lw.AL32.p, lw.chkf.p, lw.pre_f.p, lw.end_f.p, lw.slog32.p);           \
+    if (ev_fwdk) (void)hipEventRecord(ev_fwdk, st);                                                                  \
     hipLaunchKernelGGL((k_fb_itemlinks<NT>), gridit, dim3(256), 0, st, lg, m->N, lw.pre_f.p, lw.end_f.p,             \
                        lw.pre_b.p, lw.end_b.p, lw.dl_f.p, lw.lr_f.p, lw.dl_b.p, 1);                                  \
     hipLaunchKernelGGL((k_fb_stitch<NT>), gridc, dim3(256), 0, st, iv, lg, fc, m->N, lw.slog32.p, lw.end_b.p,        \
@@ -1439,6 +1443,8 @@ static int launch_fused_fb(tehmm_batch *b, const tehmm_model *m, const IntervalT
                        (double *)nullptr, (int *)nullptr, 1, b->sw.stats.p, lg, (const int *)lw.ok_f.p,              \
                        (const double *)lw.chkf.p, (double *)nullptr, lw.AL32.p, (const double *)lw.end_f.p);         \
     (void)hipEventRecord(ev_fwd, st);                                                                                \
+    }                                                                                                               \
+    if (half == 1) break;                                                                                           \
     if (estep) {                                                                                                    \
       allow_lds(k_fused_bwd<NT, LOG_, false, true>, lds_f);                                                          \
       hipLaunchKernelGGL((k_fused_bwd<NT, LOG_, false, true>), gridm, dim3(256), lds_f, st, iv, ft, lg, m->N, fc.CS, \
@@ -1453,6 +1459,10 @@ static int launch_fused_fb(tehmm_batch *b, const tehmm_model *m, const IntervalT
   if (m->ptab_log) TEHMM_FUSED_LAUNCH(true);
   else TEHMM_FUSED_LAUNCH(false);
 #undef TEHMM_FUSED_LAUNCH
+  if (half == 1) {
+    HIPCHK(hipGetLastError());
+    return TEHMM_OK;
+  }
   hipLaunchKernelGGL((k_fb_itemlinks<NT>), gridit, dim3(256), 0, st, lg, m->N, lw.pre_f.p, lw.end_f.p, lw.pre_b.p,
                      lw.end_b.p, lw.dl_f.p, lw.lr_f.p, lw.dl_b.p, 2);
   hipLaunchKernelGGL((k_fb_stitch<NT>), gridc, dim3(256), 0, st, iv, lg, fc, m->N, lw.slog32.p, lw.end_b.p,
@@ -2074,7 +2084,17 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   // Viterbi fix-up chain instead of competing with the passes that chain is waiting for (its emission
   // rows, which depend on nothing, are computed up front).
   const char *dfs = std::getenv("TEHMM_DEFER");
-  const bool defer_post = vit && postr && vspec && !(dfs && std::atoi(dfs) == 0);
+  // 0: no order, 1: behind the Viterbi passes, 2: behind the emission rows only.  Measured (ms per step, modes 1 / 2;
+  // 35 states, bench geometry): 10 Mb 15.6 / 15.9, 20 Mb 21.8 / 21.7, 30 Mb 28.3 / 26.0, 50 Mb 45.1 / 41.2, 70 Mb 60.1 /
+  // 56.3, 100 Mb 73.3 / 75.6 (mode 0: 76.0).  Below ~3 waves per SIMD the one-wave quantised pass and the emission
+  // kernel leave tails that the posterior passes fill (mode 2); on a full GPU they only take from each other and the
+  // exact chain loses its quiet partner (mode 1).
+  // Mode 3 (fused passes): the FORWARD half runs from the start, beside the emission-row kernel and the host's binade
+  // placement; the quantised pass waits for the forward pass itself and then has the GPU alone; the backward half
+  // follows it, next to the exact chain.
+  const int defer_mode = dfs ? std::atoi(dfs) : (b->total < (int64_t)85000000 ? 2 : 1);
+  const bool defer_post = vit && postr && vspec && (defer_mode == 1 || defer_mode == 3);
+  const bool split_post = defer_post && defer_mode == 3 && flane && fused_fb && vlane;
   if (postr) (void)hipEventRecord(b->ev[eP], b->sP);
   if (vlane || glane) {
     // emission rows of every position, once, item-interleaved (log rows for Viterbi, linear for fwd/bwd)
@@ -2090,8 +2110,10 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     }
     (void)hipEventRecord(b->ev[eV + 4], st);
     if (flane) {
-      (void)hipEventRecord(b->evX[0], st);
-      (void)hipStreamWaitEvent(b->sP, b->evX[0], 0);
+      if (!fused_fb) {                                  // (the fused passes compute their own emission rows)
+        (void)hipEventRecord(b->evX[0], st);
+        (void)hipStreamWaitEvent(b->sP, b->evX[0], 0);
+      }
       (void)hipEventRecord(b->ev[eP + 4], b->sP);
     }
   }
@@ -2132,9 +2154,11 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   bool wide_cp = false;                             // the chunk-parallel posterior for 64 <= N <= 128 ran
   bool wide_vit = false;                            // ... and the chunk-parallel exact Viterbi
   bool wide_pending = false;                        // a chunk-parallel posterior attempt is in flight
-  auto enqueue_posterior = [&]() -> int {
+  // half (fused passes only): 1 = the forward half now, 2 = the backward half; 0 = everything
+  auto enqueue_posterior = [&](int half = 0) -> int {
     hipStream_t st = b->sP;
-    (void)hipEventRecord(b->ev[10], st);            // start of the passes (behind any deferral wait)
+    if (half != 2) (void)hipEventRecord(b->ev[10], st);            // start of the passes (behind any deferral wait)
+    else (void)hipEventRecord(b->ev[11], st);                      // ... of the backward half
     if (flane) {
       // lane = item passes (forward, backward, links), then the two sequential chains on the
       // item-interleaved rows, then the transposing combine
@@ -2143,14 +2167,17 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       fc.scale = sw.scale.p; fc.wstart = sw.wstart.p;
       fc.link_f = lw.link_f.p; fc.glog_f = lw.glog_f.p; fc.link_b = lw.link_b.p; fc.runend_f = lw.runend_f.p;
       fc.pre_f = lw.cpre_f.p; fc.runstart_b = lw.runstart_b.p;
-      (void)hipMemsetAsync(b->dead.p, 0, (size_t)(b->n + 1) * sizeof(int), st);
-      (void)hipMemsetAsync(sw.stats.p + 2, 0, 4 * sizeof(int), st);
+      if (half != 2) {
+        (void)hipMemsetAsync(b->dead.p, 0, (size_t)(b->n + 1) * sizeof(int), st);
+        (void)hipMemsetAsync(sw.stats.p + 2, 0, 4 * sizeof(int), st);
+      }
       if (fused_fb) {
         int rcf = TEHMM_OK;
-#define CALL(NT_) rcf = launch_fused_fb<NT_>(b, m, iv, em, fc, WuF, st, b->ev[eP + 3], b->ev[eP + 1])
+#define CALL(NT_) rcf = launch_fused_fb<NT_>(b, m, iv, em, fc, WuF, st, b->ev[eP + 3], b->ev[eP + 1], false, half, half == 1 ? b->evX[1] : nullptr)
         TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
         if (rcf) return rcf;
+        if (half == 1) return TEHMM_OK;
       } else {
 #define CALL(NT_) launch_fb_lane<NT_>(b, m, iv, em, fc, WuF, st, b->ev[eP + 3])
         TEHMM_NT_DISPATCH(m->NP, CALL)
@@ -2228,7 +2255,10 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     return TEHMM_OK;
   };
   if (postr && defer_post) enqueue_emission();      // the emission rows do not wait (17 ms next to P0)
-  if (postr && defer_post && flane && fused_fb) {
+  if (split_post) {
+    rc = enqueue_posterior(1);
+    if (rc) return rc;
+  } else if (postr && defer_post && flane && fused_fb) {
     // neither do the index records of the fused passes: they only read the observations
     int rcp = TEHMM_OK;
     FusedOrder fo_unused;
@@ -2238,10 +2268,11 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     if (rcp) return rcp;
   }
   // 64 <= N <= 128 (tehmm_wide.hip.h), both results: the same order, arranged at the Viterbi enqueue below
-  const bool wide_defer = vit && postr && !vspec && !coop && m->N >= 64 && !(dfs && std::atoi(dfs) == 0);
+  const bool wide_defer = vit && postr && !vspec && !coop && m->N >= 64 && defer_mode != 0;
   if (postr && !defer_post) {
     enqueue_emission();
     if (!wide_defer) {
+      if (defer_mode == 2 && vit && vspec && (vlane || glane)) (void)hipStreamWaitEvent(b->sP, b->ev[eV + 4], 0);
       rc = enqueue_posterior();
       if (rc) return rc;
     }
@@ -2357,6 +2388,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       HIPCHK(hipMemsetAsync(sw.stats.p, 0, 2 * sizeof(int), st));
       HIPCHK(hipMemsetAsync(lw.vbad.p, 0, (size_t)std::max(1, lw.n_groups) * 64 * sizeof(int), st));
       HIPCHK(hipMemsetAsync(lw.vntie.p, 0, (size_t)std::max(1, lw.n_groups) * 64 * sizeof(int), st));
+      if (split_post) (void)hipStreamWaitEvent(st, b->evX[1], 0);     // the forward pass itself is through
 #define CALL(NT_) launch_vit_lane<NT_>(b, m, iv, vc, true, ratio, WuV, n_work, emin, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
@@ -2367,7 +2399,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       (void)hipEventRecord(b->ev[eV + 3], st);
       if (defer_post) {
         (void)hipStreamWaitEvent(b->sP, b->ev[eV + 3], 0);
-        rc = enqueue_posterior();
+        rc = enqueue_posterior(split_post ? 2 : 0);
         if (rc) return rc;
       }
 #define CALL(NT_) launch_vit_fix<NT_>(b, m, iv, em, vc, true, ratio, st)
@@ -2474,7 +2506,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       b->tnames.push_back("forward_pass");               // lane pass + links + exact forward chain
       b->tpairs.push_back({10, eP + 3});
       b->tnames.push_back("backward_posterior_pass");    // lane pass incl. the posterior rows + links
-      b->tpairs.push_back({eP + 3, eP + 1});
+      b->tpairs.push_back({split_post ? 11 : eP + 3, eP + 1});
     } else if (flane) {
       if (!vlane && !glane) {
         b->tnames.push_back("emission_rows");
