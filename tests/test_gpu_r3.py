@@ -532,3 +532,36 @@ def test_wide_viterbi_chain_forms_agree(monkeypatch):
         lp_o, path_o = oracle.decode(obs[a:b], model.log_probs, model.log_startprob, model.log_transmat, 1.0, ratios[a:b])
         assert_array_equal(got["follow"][1][a:b], path_o)
         assert got["follow"][0][i] == lp_o
+
+
+@pytest.mark.timeout(600)
+def test_posterior_viterbi_order_modes_agree(monkeypatch):
+    """TEHMM_DEFER only orders the two pipelines of tehmm_eval_batch on the GPU (posterior passes behind the Viterbi
+    passes, behind the emission rows, split around the quantised pass, or unordered): paths, scores, posteriors and
+    log-likelihoods are identical bit for bit in every mode, and equal to the oracle's on one interval."""
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    from oracle import oracle
+    model = synth.make_model(35, synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=3)
+    lens = [150000, 90000, 1, 4000, 260000]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = synth.sample_obs(model, int(offs[-1]), seed=21, missing=0.02)
+    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, 1.0, model.symbols_per_track)
+    got = {}
+    for mode in ("1", "0", "2", "3"):
+        monkeypatch.setenv("TEHMM_DEFER", mode)
+        hb = HipBatch(obs, offs)
+        res = hm.eval(hb, viterbi=True, posterior=True)
+        tm = hb.timing()
+        assert tm.get("count:viterbi_chunk_jumps", 0) > 0 and tm.get("count:forward_chunk_jumps", 0) > 0
+        got[mode] = (res["viterbi_logprob"].copy(), res["forward_logprob"].copy(), np.array(hb.paths()),
+                     np.array(hb.posteriors()))
+        hb.close()
+    monkeypatch.delenv("TEHMM_DEFER")
+    for mode in ("0", "2", "3"):
+        for a, b in zip(got[mode], got["1"]):
+            assert_array_equal(a, b)
+    a, b = int(offs[1]), int(offs[2])
+    lp_o, path_o = oracle.decode(obs[a:b], model.log_probs, model.log_startprob, model.log_transmat, 1.0, None)
+    assert_array_equal(got["3"][2][a:b], path_o)
+    assert got["3"][0][1] == lp_o
