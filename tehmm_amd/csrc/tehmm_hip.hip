@@ -2092,7 +2092,11 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   // Mode 3 (fused passes): the FORWARD half runs from the start, beside the emission-row kernel and the host's binade
   // placement; the quantised pass waits for the forward pass itself and then has the GPU alone; the backward half
   // follows it, next to the exact chain.
-  const int defer_mode = dfs ? std::atoi(dfs) : (b->total < (int64_t)85000000 ? 2 : 1);
+  // Where ONE chain dominates (a single 10 Mb interval: 16.0 / 18.1) mode 1 keeps the posterior passes as its partner.
+  int64_t longest = 0;
+  for (int i = 0; i < b->n; ++i) longest = std::max<int64_t>(longest, b->h_len[(size_t)i]);
+  const bool mid_size = b->total >= (int64_t)25000000 && b->total < (int64_t)85000000 && 4 * longest <= b->total;
+  const int defer_mode = dfs ? std::atoi(dfs) : (mid_size ? 2 : 1);
   const bool defer_post = vit && postr && vspec && (defer_mode == 1 || defer_mode == 3);
   const bool split_post = defer_post && defer_mode == 3 && flane && fused_fb && vlane;
   if (postr) (void)hipEventRecord(b->ev[eP], b->sP);
