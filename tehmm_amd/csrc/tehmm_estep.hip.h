@@ -33,6 +33,12 @@
 #include <type_traits>
 #include "tehmm_fused.hip.h"
 
+// the one-hot product's instruction: bf16 16x16x16 (default), fp32 16x16x4 (-DTEHMM_ESTEP_HIST_F32) or fp64 16x16x4
+// (-DTEHMM_ESTEP_HIST_F64, the first version)
+#if !defined(TEHMM_ESTEP_HIST_F64) && !defined(TEHMM_ESTEP_HIST_F32) && !defined(TEHMM_ESTEP_HIST_BF16)
+#define TEHMM_ESTEP_HIST_BF16 1
+#endif
+
 namespace tehmm {
 
 // Track partition of the reduction (built on the host, estep_build_groups):
@@ -235,19 +241,28 @@ __device__ __forceinline__ void estep_hist_mfma_run(const IntervalTab &iv, const
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const EstepTile tc = estep_tile<NT>(iv, lg, tile, i16, KP, obs);
     if (tc.nsmax <= 0) continue;
-    // the four items this lane contracts over (item 4 kk + g_k of the tile): observation rows and lengths
+    // the four items this lane contracts over -- item 4 kk + g_k of the tile for the 16x16x4 instructions (k = lane >> 4),
+    // items 4 g_k + kk for the 16x16x16 bf16 one (a lane holds four consecutive k) --: observation rows and lengths
     int64_t oo[4];
     int nsk[4];
     const int64_t myoff = tc.orow - obs;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
+#ifdef TEHMM_ESTEP_HIST_BF16
+      const int src = 4 * g_k + kk;
+#else
       const int src = 4 * kk + g_k;                                 // lane `src` holds that item's data
+#endif
       nsk[kk] = __shfl(tc.ns, src);
       const unsigned lo = (unsigned)__shfl((int)(unsigned)(unsigned long long)myoff, src);
       const unsigned hi = (unsigned)__shfl((int)(unsigned)((unsigned long long)myoff >> 32), src);
       oo[kk] = (int64_t)(((unsigned long long)hi << 32) | lo);
     }
+#ifdef TEHMM_ESTEP_HIST_BF16
+    const int64_t gb2 = tc.tb2 + g_kq * 16 + 4 * g_k;              // + kk: the lane's four items are consecutive float2
+#else
     const int64_t gb2 = tc.tb2 + g_kq * 16 + g_k;
+#endif
     // Two steps are on their way at any time (buffers 0 / 1): the wave is alone on its SIMD (its accumulators take
     // the register file), so nothing else hides the latency of the gamma rows and observation bytes -- with ONE step
     // in flight a tile step took 4.8 us for 1.1 us of matrix instructions
@@ -263,7 +278,11 @@ __device__ __forceinline__ void estep_hist_mfma_run(const IntervalTab &iv, const
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           const int pc = min(4 * q + g_pp, P - 1);
+#ifdef TEHMM_ESTEP_HIST_BF16
+          xg[B][q][kk] = gam2[gb2 + (int64_t)s * (256 * P) + pc * 64 + kk];
+#else
           xg[B][q][kk] = gam2[gb2 + (int64_t)s * (256 * P) + pc * 64 + 4 * kk];      // (raw: selected when consumed)
+#endif
         }
 #pragma unroll
       for (int r = 0; r < RT; ++r)
@@ -275,7 +294,52 @@ __device__ __forceinline__ void estep_hist_mfma_run(const IntervalTab &iv, const
     };
     auto step = [&](int s, auto bsel) {
       constexpr int B = decltype(bsel)::value;
-#ifdef TEHMM_ESTEP_HIST_F64
+#ifdef TEHMM_ESTEP_HIST_BF16
+      // ONE matrix instruction contracts all 16 items of the tile (v_mfma_f32_16x16x16_bf16: a lane holds four
+      // consecutive k).  The one-hot operand is exact in bf16; a float gamma is the exact sum of three bf16 pieces (top
+      // 8 bits of the value, of the remainder, the rest), so three instructions per (row tile, state tile) give the same
+      // single-precision sums as the 16x16x4 form with a third of the operand building per matrix instruction.
+      typedef short estep_s4 __attribute__((ext_vector_type(4)));
+      typedef unsigned estep_u2 __attribute__((ext_vector_type(2)));
+      estep_s4 a[RT], w[NTILE][3];
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        unsigned h[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) h[kk] = ((s < nsk[kk]) & (sy[B][r][kk] == rsym[r])) ? 0x3F80u : 0u;      // bf16 1.0
+        const estep_u2 pk = {h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+        a[r] = __builtin_bit_cast(estep_s4, pk);
+      }
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) {
+        unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const float g = (t & 1) ? xg[B][t >> 1][kk].y : xg[B][t >> 1][kk].x;
+          p1[kk] = __float_as_uint(g) & 0xFFFF0000u;
+          const float r1 = g - __uint_as_float(p1[kk]);                 // exact
+          p2[kk] = __float_as_uint(r1) & 0xFFFF0000u;
+          const float r2 = r1 - __uint_as_float(p2[kk]);                // exact, <= 8 significant bits
+          p3[kk] = __float_as_uint(r2);
+        }
+        // the upper halves of two dwords side by side: v_perm_b32 (bytes 2, 3 of the second operand, then of the first)
+        const estep_u2 q1 = {__builtin_amdgcn_perm(p1[1], p1[0], 0x07060302u), __builtin_amdgcn_perm(p1[3], p1[2], 0x07060302u)};
+        const estep_u2 q2 = {__builtin_amdgcn_perm(p2[1], p2[0], 0x07060302u), __builtin_amdgcn_perm(p2[3], p2[2], 0x07060302u)};
+        const estep_u2 q3 = {__builtin_amdgcn_perm(p3[1], p3[0], 0x07060302u), __builtin_amdgcn_perm(p3[3], p3[2], 0x07060302u)};
+        w[t][0] = __builtin_bit_cast(estep_s4, q1);
+        w[t][1] = __builtin_bit_cast(estep_s4, q2);
+        w[t][2] = __builtin_bit_cast(estep_s4, q3);
+      }
+      if (s + 2 < tc.nsmax) request(s + 2, bsel);
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+          for (int tw = 0; tw < NTILE; ++tw)
+            acc32[r][tw] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[r], w[tw][pc], acc32[r][tw], 0, 0, 0);
+      if ((s & 7) == 7) flush32();
+#elif defined(TEHMM_ESTEP_HIST_F64)
       double a[4][RT], w[4][NTILE];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
@@ -376,6 +440,10 @@ __global__ __launch_bounds__(TEHMM_ESTEP_HW * 64) void k_estep_hist_mfma(Interva
   const int mine = max(0, min(rtw, nrt - wv * rtw));
   if (mine == 2) estep_hist_mfma_run<NT, 2>(iv, lg, egp, N, KP, obs, gam32, gstat, rt0);
   else if (mine == 1) estep_hist_mfma_run<NT, 1>(iv, lg, egp, N, KP, obs, gam32, gstat, rt0);
+#if TEHMM_ESTEP_HW < 4
+  else if (mine == 3) estep_hist_mfma_run<NT, 3>(iv, lg, egp, N, KP, obs, gam32, gstat, rt0);
+  else if (mine == 4) estep_hist_mfma_run<NT, 4>(iv, lg, egp, N, KP, obs, gam32, gstat, rt0);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
