@@ -382,19 +382,24 @@ def extras(args, model, hm, hb, obs, offs, lens, device, torch, mk_model):
         mask = (np.arange(model.n_states) % 3 == 0).astype(np.float64)
         for tag in ("full_posteriors_first_call", "full_posteriors", "masked_sum"):
             # (the host is shared: the steady-state figures are the best of three fresh batches, all three on the record)
-            times = []
+            times, parts = [], []
             for _rep in range(1 if tag.endswith("first_call") else 3):
                 t1 = time.perf_counter()
                 hb2 = HipBatch(host_obs, o2)
+                t2 = time.perf_counter()
                 hm.eval(hb2, viterbi=True, posterior=True)
+                t3 = time.perf_counter()
                 p = hb2.paths()
                 q = hb2.posteriors() if tag.startswith("full_posteriors") else hb2.posterior_masksum(mask)
-                times.append(time.perf_counter() - t1)
+                t4 = time.perf_counter()
+                times.append(t4 - t1)
+                parts.append([round((t2 - t1) * 1e3, 1), round((t3 - t2) * 1e3, 1), round((t4 - t3) * 1e3, 1)])
                 nbytes = int(p.nbytes + q.nbytes)
                 hb2.close()
                 del p, q
             ex["end_to_end_pcie_" + tag] = rate(n2, min(times), positions=n2, bytes_d2h=nbytes,
                                                 ms_all=[round(t * 1e3, 1) for t in times],
+                                                ms_create_eval_fetch=parts[int(np.argmin(times))],
                                                 note="fresh batch: H2D of the observations, workspace allocation, "
                                                      "evaluation, D2H into pinned host memory from the library's pool"
                                                      + (" (first call: the pool is empty, pinning included)"
