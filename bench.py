@@ -400,6 +400,7 @@ def extras(args, model, hm, hb, obs, offs, lens, device, torch, mk_model):
             ex["end_to_end_pcie_" + tag] = rate(n2, min(times), positions=n2, bytes_d2h=nbytes,
                                                 ms_all=[round(t * 1e3, 1) for t in times],
                                                 ms_create_eval_fetch=parts[int(np.argmin(times))],
+                                                ms_create_eval_fetch_all=parts,
                                                 note="fresh batch: H2D of the observations, workspace allocation, "
                                                      "evaluation, D2H into pinned host memory from the library's pool"
                                                      + (" (first call: the pool is empty, pinning included)"
