@@ -1805,6 +1805,8 @@ static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalT
   // WHILE it runs, waiting for each chunk's ready flag
   const char *pls = std::getenv("TEHMM_WIDE_POLL");
   const bool poll = head && b->n <= 64 && !(pls && std::atoi(pls) == 0);
+  // polls (~2.7 us each) a chain may spend waiting: the pass needs ~1.4 us per chunk with the GPU to itself, allow tenfold
+  const int spin_limit = (int)std::min<int64_t>(1 << 20, std::max<int64_t>(1 << 13, (int64_t)nc * 6));
   if (head) {
     w.h_hstop.assign((size_t)b->n, 0);
     for (int i = 0; i < b->n; ++i) {
@@ -1832,14 +1834,14 @@ static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalT
                          (const double *)m->pi.p, (const double *)b->ratios.p, b->TBW, b->tb.p, b->last_state.p, b->vit_lp.p,
                          sw.stats.p, (const double *)w.rows2.p, (const double *)w.BL.p, w.sel_from.p, w.sel_hyp.p,
                          (const double *)w.pre.p, phase, (const int64_t *)w.hstop.p, w.hvec.p, w.hflag.p,
-                         (const int *)(phase == 2 && poll ? w.ready.p : nullptr));
+                         (const int *)(phase == 2 && poll ? w.ready.p : nullptr), spin_limit);
     } else {
       allow_lds(k_vit_wide_fix<false>, ldsf);
       hipLaunchKernelGGL((k_vit_wide_fix<false>), dim3(b->n), dim3(256), ldsf, s2, iv, em, vc, m->N, m->NP, (const double *)m->lt.p,
                          (const double *)m->pi.p, (const double *)nullptr, b->TBW, b->tb.p, b->last_state.p, b->vit_lp.p,
                          sw.stats.p, (const double *)w.rows2.p, (const double *)w.BL.p, w.sel_from.p, w.sel_hyp.p,
                          (const double *)w.pre.p, phase, (const int64_t *)w.hstop.p, w.hvec.p, w.hflag.p,
-                         (const int *)(phase == 2 && poll ? w.ready.p : nullptr));
+                         (const int *)(phase == 2 && poll ? w.ready.p : nullptr), spin_limit);
     }
   };
   if (head) {

@@ -865,7 +865,7 @@ void k_vit_wide_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, int NP, con
                     const double *tratios, int TBW, uint8_t *tb, int *last_state, double *logprob, int *stats,
                     const double *rows2, const double *__restrict__ BL, int64_t *sel_from, int *sel_hyp,
                     const double *pre, int phase, const int64_t *__restrict__ hstop, double *hvec, int *hflag,
-                    const int *ready = nullptr) {
+                    const int *ready = nullptr, int spin_limit = 1 << 19) {
   extern __shared__ double sm[];
   constexpr int W = TEHMM_WIDE_W, QM = TEHMM_WIDE_QM;
   double *ring = sm;
@@ -910,11 +910,13 @@ void k_vit_wide_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, int NP, con
   // waits for that flag: thread 0 polls, the workgroup meets at a barrier, every thread then fences (acquire, agent
   // scope) so that no stale cache line answers for the chunk's rows.  The pass does not depend on the chain and the
   // host launches this form only when the chain's workgroups cannot fill the GPU, so the wait always ends; the spin
-  // budget (about a second per interval) is a safety net behind which the chunk is simply walked exactly -- its quantised traceback bytes
+  // budget (the host's estimate of the pass, tenfold) is a safety net behind which the chunk is simply walked exactly -- its quantised traceback bytes
   // live in their own buffers (k_wide_tb_select), so a late writer cannot disturb the exact ones.
   __shared__ int s_rdy;
   int64_t lastready = -1;
-  int spin_budget = 1 << 19;         // (thread 0) polls left for the whole interval: ~1 s of waiting at most
+  int spin_budget = spin_limit;      // (thread 0) polls left for the whole interval, ~2.7 us each: the host allows about ten
+                                     // times what the pass should need (under a profiler that serialises kernels the pass
+                                     // cannot run beside the chain at all: the budget is what that costs)
   auto wait_chunk = [&](int64_t c) -> bool {
     if (!ready || lastready == c) return true;
     __syncthreads();
