@@ -146,6 +146,11 @@ int tehmm_batch_get_posteriors(tehmm_batch_t *batch, int64_t row0, int64_t row1,
  * library -- pinning is the slow part -- up to 24 GB. */
 int tehmm_host_alloc(size_t bytes, void **out);
 int tehmm_host_free(void *ptr);
+/* The library also keeps the DEVICE blocks of destroyed batches for the next batch (a fresh batch per call allocates the
+ * same workspaces again; hipMalloc of memory the process has just returned can cost hundreds of milliseconds): up to
+ * TEHMM_DEVICE_POOL_GB (environment, default 48, 0 = no caching).  tehmm_trim_pools returns every cached device and
+ * pinned host block to the system (call it before handing the GPU to another allocator that needs the room). */
+int tehmm_trim_pools(void);
 /* Device pointers of the same buffers (valid until the batch is destroyed or re-evaluated). */
 int tehmm_batch_device_ptrs(tehmm_batch_t *batch, void **paths_i64, void **posteriors_f64);
 

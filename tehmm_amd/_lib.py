@@ -68,6 +68,7 @@ SIGNATURES = {
     "tehmm_batch_get_posteriors": (c_int, [vp, c_i64, c_i64, f64p]),
     "tehmm_host_alloc": (c_int, [ctypes.c_size_t, ctypes.POINTER(vp)]),
     "tehmm_host_free": (c_int, [vp]),
+    "tehmm_trim_pools": (c_int, []),
     "tehmm_batch_device_ptrs": (c_int, [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]),
     "tehmm_estep_batch": (c_int, [vp, vp, c_int, f64p, f64p, f64p, f64p]),
     "tehmm_batch_last_timing": (c_int, [vp, c_int, ctypes.POINTER(ctypes.c_char_p), f64p]),
@@ -127,6 +128,11 @@ class _PinnedBlock(object):
         if getattr(self, "ptr", None) and _lib is not None:
             _lib.tehmm_host_free(self.ptr)
             self.ptr = None
+
+
+def trim_pools():
+    """Return the library's cached device blocks and pinned host blocks to the system."""
+    check(load().tehmm_trim_pools(), "tehmm_trim_pools")
 
 
 def pinned_empty(shape, dtype):

@@ -41,26 +41,129 @@ int fail(int code, const std::string &msg) {
       return fail(TEHMM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));        \
   } while (0)
 
+// Device blocks of destroyed batches are kept for the next batch: a fresh batch per call (teHmmEval walks a genome in
+// chunks) allocates the same ~17 GB of workspaces every time, and hipMalloc of memory the process has just given back
+// costs up to half a second on some hosts (20 Mb batch: 24 ms of evaluation behind 500 ms of allocation).  Blocks of
+// at least 1 MB are rounded to 2 MB multiples and cached up to TEHMM_DEVICE_POOL_GB (default 48, 0 = off); a request
+// takes the smallest cached block that is not more than half again its size; when hipMalloc fails the cache is
+// emptied and the request tried again.  Releasing waits for the device like hipFree does, so a block never changes
+// hands under a running kernel.  tehmm_trim_pools() gives everything back.
+struct DevPool {
+  std::mutex mu;
+  std::vector<std::pair<void *, size_t>> free_blocks;
+  size_t cached_bytes = 0;
+};
+static DevPool &dev_pool() {
+  static DevPool *p = new DevPool();       // (never destroyed: no hipFree behind the runtime's back at exit)
+  return *p;
+}
+static size_t dev_pool_cap() {
+  static const size_t cap = [] {
+    const char *s = std::getenv("TEHMM_DEVICE_POOL_GB");
+    const double gb = s ? std::atof(s) : 48.0;
+    return gb > 0.0 ? (size_t)(gb * 1073741824.0) : (size_t)0;
+  }();
+  return cap;
+}
+constexpr size_t kDevPoolMin = (size_t)1 << 20, kDevPoolGran = (size_t)2 << 20;
+static size_t dev_pool_trim() {
+  DevPool &dp = dev_pool();
+  std::vector<std::pair<void *, size_t>> blocks;
+  {
+    std::lock_guard<std::mutex> lk(dp.mu);
+    blocks.swap(dp.free_blocks);
+    dp.cached_bytes = 0;
+  }
+  size_t freed = 0;
+  for (auto &b : blocks) {
+    (void)hipFree(b.first);
+    freed += b.second;
+  }
+  return freed;
+}
+static size_t dev_pool_cached() {
+  DevPool &dp = dev_pool();
+  std::lock_guard<std::mutex> lk(dp.mu);
+  return dp.cached_bytes;
+}
+// *block_bytes = size of the block handed out (what dev_free must be told)
+static hipError_t dev_alloc(void **out, size_t bytes, size_t *block_bytes) {
+  const bool pooled = bytes >= kDevPoolMin && dev_pool_cap() > 0;
+  const size_t need = pooled ? (bytes + kDevPoolGran - 1) / kDevPoolGran * kDevPoolGran : bytes;
+  if (pooled) {
+    DevPool &dp = dev_pool();
+    std::lock_guard<std::mutex> lk(dp.mu);
+    size_t best = SIZE_MAX;
+    for (size_t i = 0; i < dp.free_blocks.size(); ++i)
+      if (dp.free_blocks[i].second >= need && dp.free_blocks[i].second <= need + need / 2 &&
+          (best == SIZE_MAX || dp.free_blocks[i].second < dp.free_blocks[best].second))
+        best = i;
+    if (best != SIZE_MAX) {
+      *out = dp.free_blocks[best].first;
+      *block_bytes = dp.free_blocks[best].second;
+      dp.cached_bytes -= dp.free_blocks[best].second;
+      dp.free_blocks.erase(dp.free_blocks.begin() + (long)best);
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(out, need);
+  if (e != hipSuccess && dev_pool_cached() > 0) {
+    (void)hipGetLastError();
+    (void)dev_pool_trim();
+    e = hipMalloc(out, need);
+  }
+  *block_bytes = e == hipSuccess ? need : 0;
+  return e;
+}
+static void dev_free(void *p, size_t block_bytes) {
+  if (!p) return;
+  if (block_bytes >= kDevPoolMin && dev_pool_cap() > 0) {
+    (void)hipDeviceSynchronize();             // what hipFree would do: nothing on the device still uses the block
+    DevPool &dp = dev_pool();
+    std::lock_guard<std::mutex> lk(dp.mu);
+    if (dp.cached_bytes + block_bytes <= dev_pool_cap()) {
+      dp.free_blocks.emplace_back(p, block_bytes);
+      dp.cached_bytes += block_bytes;
+      return;
+    }
+  }
+  (void)hipFree(p);
+}
+// free device memory as the workspace decisions should see it: what the driver reports plus what the pool holds
+static hipError_t dev_mem_info(size_t *free_b, size_t *total_b) {
+  hipError_t e = hipMemGetInfo(free_b, total_b);
+  if (e == hipSuccess) *free_b += dev_pool_cached();
+  return e;
+}
+
 // RAII device buffer
 template <typename T>
 struct DBuf {
   T *p = nullptr;
   size_t n = 0;
+  size_t block = 0;            // bytes of the device block behind p (dev_alloc)
   DBuf() = default;
   DBuf(const DBuf &) = delete;
   DBuf &operator=(const DBuf &) = delete;
   ~DBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) dev_free(p, block);
     p = nullptr;
     n = 0;
     cap = 0;
+    block = 0;
   }
   hipError_t alloc(size_t count) {
     release();
     n = count;
     if (count == 0) return hipSuccess;
-    return hipMalloc((void **)&p, count * sizeof(T));
+    void *q = nullptr;
+    size_t blk = 0;
+    hipError_t e = dev_alloc(&q, count * sizeof(T), &blk);
+    if (e != hipSuccess) return e;
+    p = (T *)q;
+    block = blk;
+    return hipSuccess;
   }
   hipError_t upload(const T *h, size_t count) {
     hipError_t e = alloc(count);
@@ -1640,7 +1743,7 @@ static int posterior_wide_cp(tehmm_batch *b, const tehmm_model *m, const Interva
     {
       // emission rows (8 NPW bytes per position) + float alpha' rows (4 NPW): the sequential kernels need neither
       size_t free_b = 0, total_b = 0;
-      HIPCHK(hipMemGetInfo(&free_b, &total_b));
+      HIPCHK(dev_mem_info(&free_b, &total_b));
       if ((double)b->total * NPW * 12.5 + (double)(b->total / L + b->n + 64) * NPW * 40.0 > 0.9 * (double)free_b) return TEHMM_OK;
     }
     std::vector<int> h_iv;
@@ -1718,7 +1821,7 @@ static int viterbi_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalT
     // workspaces: log rows (1 KB per position), two sets of traceback bytes, recorded rows -- if they do not fit next
     // to what the batch holds already, the sequential kernels (which need none of it) take the call
     size_t free_b = 0, total_b = 0;
-    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    HIPCHK(dev_mem_info(&free_b, &total_b));
     const double need = (double)b->total_pad * (TEHMM_WIDE_S * 8.0 + 2.0 * b->TBW) * 1.25 +
                         (double)nc * ((sw.CS / TEHMM_VROW) + 2.0) * m->NP * 8.0 * 1.25;
     if (need > 0.9 * (double)free_b) return TEHMM_OK;
@@ -2040,7 +2143,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     // for the float rows of P0) must fit next to the results; otherwise do without the fp64 log rows, and
     // failing that stay with the [T][N] speculative passes
     size_t free_b = 0, total_b = 0;
-    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    HIPCHK(dev_mem_info(&free_b, &total_b));
     const double per = (double)b->total * m->NP * 8.0;
     const double fb_units = fspec ? (fused_fb ? 0.7 : 3.2) : 0.0, p0_units = (vspec && !fused_fb) ? 0.5 : 0.0;
     b->lw.no_vlane = per * (fb_units + p0_units + 1.0) > 0.85 * (double)free_b;
@@ -2049,7 +2152,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   if (LS > 0 && want_vlane && !b->lw.no_vlane && !b->lw.B.p && (b->lw.AL.p || b->lw.AL32.p || b->lw.B32.p)) {
     // workspaces of an earlier call exist already: the fp64 (+ float) log rows must still fit
     size_t free_b = 0, total_b = 0;
-    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    HIPCHK(dev_mem_info(&free_b, &total_b));
     if ((double)b->total * m->NP * 8.0 * 1.6 > 0.85 * (double)free_b) b->lw.no_vlane = true;
   }
   if (b->lw.no_vlane) want_vlane = false;
@@ -2763,6 +2866,19 @@ int tehmm_host_free(void *p) {
   return TEHMM_OK;
 }
 
+int tehmm_trim_pools(void) {
+  (void)hipDeviceSynchronize();
+  (void)dev_pool_trim();
+  std::vector<std::pair<void *, size_t>> blocks;
+  {
+    std::lock_guard<std::mutex> lk(g_pinned.mu);
+    blocks.swap(g_pinned.free_blocks);
+    g_pinned.cached_bytes = 0;
+  }
+  for (auto &blk : blocks) (void)hipHostFree(blk.first);
+  return TEHMM_OK;
+}
+
 int tehmm_batch_get_paths(tehmm_batch_t *b, int64_t row0, int64_t row1, int64_t *paths) {
   if (!b || !paths || row0 < 0 || row1 < row0 || row1 > b->total)
     return fail(TEHMM_ERR_ARG, "tehmm_batch_get_paths: bad argument");
@@ -3117,7 +3233,7 @@ static int estep_fused(tehmm_model_t *m, tehmm_batch_t *b, double *dev_stats, do
   if (!(lw.AL32.p && lw.GAM32.p && lw.L == LS && lw.CS == CS && lw.NP == m->NP)) {
     // three float rows + index records per position must fit; otherwise the grouped sequential path
     size_t free_b = 0, total_b = 0;
-    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    HIPCHK(dev_mem_info(&free_b, &total_b));
     const double per = (double)b->total * (3.0 * 32.0 * al32_pairs(m->NP) + 40.0) * 1.15;
     if (per > 0.85 * (double)free_b) return TEHMM_OK;
   }
@@ -3235,7 +3351,7 @@ static int estep_accumulate(tehmm_model_t *m, tehmm_batch_t *b, int use_ratios, 
   // (3 x 8N + 4 bytes per position, 40 % of the free HBM): the 3 Gb training sets of config 4
   // never materialise whole-genome lattices.
   size_t free_b = 0, total_b = 0;
-  (void)hipMemGetInfo(&free_b, &total_b);
+  (void)dev_mem_info(&free_b, &total_b);
   int64_t budget_bytes = (int64_t)((double)(free_b + (size_t)b->ew.rows_cap * (24 * N + 4)) * 0.4);
   if (budget_bytes < (4ll << 30)) budget_bytes = 4ll << 30;
   const int64_t budget_rows = std::max<int64_t>(budget_bytes / (24 * N + 4), 1);
