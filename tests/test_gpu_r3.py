@@ -565,3 +565,38 @@ def test_posterior_viterbi_order_modes_agree(monkeypatch):
     lp_o, path_o = oracle.decode(obs[a:b], model.log_probs, model.log_startprob, model.log_transmat, 1.0, None)
     assert_array_equal(got["3"][2][a:b], path_o)
     assert got["3"][0][1] == lp_o
+
+
+@pytest.mark.timeout(600)
+def test_device_block_pool_reuse_and_trim():
+    """Workspaces of a destroyed batch are handed to the next one (DevPool, tehmm_trim_pools): a second fresh batch of
+    the same shape -- on blocks full of the first one's data -- and a third one after the pools were emptied give
+    the first batch's results bit for bit; a batch of another model in between does not disturb them."""
+    from tehmm_amd import _lib, synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    model = synth.make_model(35, synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=8)
+    other = synth.make_model(20, (3, 5, 7), (), seed=9)
+    lens = [70000, 1, 123456, 300]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = synth.sample_obs(model, int(offs[-1]), seed=4, missing=0.02)
+    obs_o = synth.sample_obs(other, 50000, seed=5)
+    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, 1.0, model.symbols_per_track)
+    ho = HipModel(other.log_transmat, other.log_startprob, other.log_probs, 1.0, other.symbols_per_track)
+
+    def run():
+        hb = HipBatch(obs, offs)
+        res = hm.eval(hb, viterbi=True, posterior=True)
+        out = (res["viterbi_logprob"].copy(), res["forward_logprob"].copy(), np.array(hb.paths()), np.array(hb.posteriors()))
+        hb.close()
+        return out
+
+    first = run()
+    hbo = HipBatch(obs_o, np.asarray([0, 50000], dtype=np.int64))
+    ho.eval(hbo, viterbi=True, posterior=True)
+    hbo.close()
+    second = run()
+    _lib.trim_pools()
+    third = run()
+    for a, b, c in zip(first, second, third):
+        assert_array_equal(a, b)
+        assert_array_equal(a, c)
