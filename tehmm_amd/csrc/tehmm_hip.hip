@@ -1725,7 +1725,7 @@ static int posterior_wide_finish(tehmm_batch *b, const tehmm_model *m, const Int
 // (*pending = true; nothing enqueued otherwise: short batches, TEHMM_WIDE_CP=0); posterior_wide_finish delivers the
 // verdict, so the exact Viterbi of the same evaluation can be enqueued in between and share the GPU with the passes.
 static int posterior_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em, hipStream_t st,
-                             hipEvent_t mid, bool *pending) {
+                             hipEvent_t mid, bool *pending, const double *log_rows = nullptr) {
   *pending = false;
   const char *ws = std::getenv("TEHMM_WIDE_CP");
   if (ws && std::atoi(ws) == 0) return TEHMM_OK;
@@ -1778,7 +1778,11 @@ static int posterior_wide_cp(tehmm_batch *b, const tehmm_model *m, const Interva
   lg.n_items = w.n_items; lg.n_groups = w.n_groups; lg.L = L;
   const EmisTab emg = without_lds_tables(em);
   HIPCHK(hipMemsetAsync(w.flags.p, 0, 4 * sizeof(int), st));
-  hipLaunchKernelGGL(k_wide_emis, dim3((w.n_items + 3) / 4), dim3(256), 0, st, iv, emg, lg, m->N, NPW, w.E.p, w.ms.p, w.flags.p);
+  if (log_rows)      // the exact Viterbi of this evaluation has the log rows already (k_wide_logrows): no second gather
+    hipLaunchKernelGGL(k_wide_emis_from_log, dim3((w.n_items + 3) / 4), dim3(256), 0, st, iv, lg, m->N, NPW, log_rows, w.E.p, w.ms.p,
+                       w.flags.p);
+  else
+    hipLaunchKernelGGL(k_wide_emis, dim3((w.n_items + 3) / 4), dim3(256), 0, st, iv, emg, lg, m->N, NPW, w.E.p, w.ms.p, w.flags.p);
   // warm-up: 128 positions to begin with (it may exceed the item length: the passes read the emission rows of the
   // interval, not of the item), or what the last evaluation with this model needed
   constexpr int kWuMax = 1024;
@@ -2338,7 +2342,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     } else {
       // 64 <= N <= 128: the chunk-parallel passes are enqueued; their verdict is read behind the Viterbi enqueue
       // (finish_wide_posterior), so the two pipelines share the GPU
-      rc = posterior_wide_cp(b, m, iv, em, st, b->ev[eP + 1], &wide_pending);
+      rc = posterior_wide_cp(b, m, iv, em, st, b->ev[eP + 1], &wide_pending, wide_vit ? (const double *)b->ww.BL.p : nullptr);
       if (rc) return rc;
       if (!wide_pending) {
         if (SPL == 1) launch_posterior<1>(b, m, iv, em, st, b->ev[eP + 1]);

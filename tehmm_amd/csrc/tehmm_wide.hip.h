@@ -25,6 +25,8 @@
 #include <type_traits>
 #include "tehmm_fused.hip.h"
 
+#define TEHMM_WIDE_S 128            // row stride of the wide log-row buffer and of the LDS table
+
 namespace tehmm {
 
 template <int NPW>
@@ -48,6 +50,31 @@ __global__ __launch_bounds__(256) void k_wide_emis(IntervalTab iv, EmisTab em, L
   for (int s = 0; s < len; ++s) {
     double x[2];
     emis_log_wide(em, em.tab, p0 + t0 + s, lane, N, x);        // (no LDS copy of the small tracks: ldsbase < 0 everywhere)
+    const double m = row_max<2>(x, lane, N);
+    const bool good = m > -1e20;
+    bad = bad | !good;
+    double *dst = E + (r0 + t0 + s) * (int64_t)NPW;
+    dst[lane] = (good && lane < N) ? exp_nonpos(x[0] - m) : 0.0;
+    if (lane + 64 < NPW) dst[lane + 64] = (good && lane + 64 < N) ? exp_nonpos(x[1] - m) : 0.0;
+    if (lane == 0) ms[r0 + t0 + s] = good ? m : 0.0;
+  }
+  if (bad && lane == 0) atomicAdd(&flags[0], 1);
+}
+
+// The same from the log rows the exact Viterbi of the same evaluation has already written (k_wide_logrows: BL [internal
+// position][128]): both results requested -> the ten table gathers per position are done once.
+__global__ __launch_bounds__(256) void k_wide_emis_from_log(IntervalTab iv, LaneGeom lg, int N, int NPW,
+                                                            const double *__restrict__ BL, double *E, double *ms, int *flags) {
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= lg.n_items) return;
+  const int id = lg.item_iv[item];
+  const int64_t t0 = lg.item_t0[item], T = iv.len[id], p0 = iv.pos0[id], r0 = iv.out0[id];
+  const int len = (int)min((int64_t)lg.L, T - t0);
+  bool bad = false;
+  for (int s = 0; s < len; ++s) {
+    const double *src = BL + (p0 + t0 + s) * TEHMM_WIDE_S;
+    double x[2] = {src[lane], src[lane + 64]};
     const double m = row_max<2>(x, lane, N);
     const bool good = m > -1e20;
     bad = bad | !good;
@@ -321,7 +348,6 @@ __global__ __launch_bounds__(64) void k_wide_loglik(IntervalTab iv, LaneGeom lg,
 // Rounding ties (b or a ratio product exactly between two grid points) end a speculative segment as in
 // tehmm_spec.hip.h; the chain lands exactly on them.
 // ==========================================================================================================
-#define TEHMM_WIDE_S 128            // row stride of the wide log-row buffer and of the LDS table
 #define TEHMM_WIDE_MAXTT 8          // transition-table entries per binade that may be rounding ties
 
 __device__ __forceinline__ double wide_readlane(double v, int l) {
