@@ -4,6 +4,7 @@
 #include "tehmm_kernels.hip.h"
 #include "tehmm_coop.hip.h"
 #include "tehmm_lane.hip.h"
+#include "tehmm_lane3.hip.h"
 #include "tehmm_aux.hip.h"
 #include "tehmm_fused.hip.h"
 #include "tehmm_estep.hip.h"
@@ -44,95 +45,140 @@ int fail(int code, const std::string &msg) {
 // Device blocks of destroyed batches are kept for the next batch: a fresh batch per call (teHmmEval walks a genome in
 // chunks) allocates the same ~17 GB of workspaces every time, and hipMalloc of memory the process has just given back
 // costs up to half a second on some hosts (20 Mb batch: 24 ms of evaluation behind 500 ms of allocation).  Blocks of
-// at least 1 MB are rounded to 2 MB multiples and cached up to TEHMM_DEVICE_POOL_GB (default 48, 0 = off); a request
-// takes the smallest cached block that is not more than half again its size; when hipMalloc fails the cache is
-// emptied and the request tried again.  Releasing waits for the device like hipFree does, so a block never changes
-// hands under a running kernel.  tehmm_trim_pools() gives everything back.
+// at least 1 MB are rounded to 2 MB multiples and cached PER DEVICE (a block is only ever handed out, synchronised or
+// freed with its own device current) up to TEHMM_DEVICE_POOL_GB per device (default: an eighth of the device's memory,
+// at most 48; 0 = off); a request takes the smallest cached block of its device that is not more than half again its
+// size; when hipMalloc fails the device's cache is emptied and the request tried again.  Releasing waits for the
+// block's device like hipFree does, so a block never changes hands under a running kernel.  The cache is invisible to
+// other allocators in the process (torch): call tehmm_trim_pools() before handing the device to them.
+struct DevBlock {
+  void *p;
+  size_t bytes;
+  int dev;
+};
 struct DevPool {
   std::mutex mu;
-  std::vector<std::pair<void *, size_t>> free_blocks;
-  size_t cached_bytes = 0;
+  std::vector<DevBlock> free_blocks;
+  std::vector<size_t> cached;              // bytes cached per device
+  std::vector<size_t> cap;                 // per-device cap (0 = not yet known)
 };
 static DevPool &dev_pool() {
   static DevPool *p = new DevPool();       // (never destroyed: no hipFree behind the runtime's back at exit)
   return *p;
 }
+static int dev_current() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; }
+  return d;
+}
+// cap of the CURRENT device's cache (needs the device for the default: a fraction of its memory)
 static size_t dev_pool_cap() {
-  static const size_t cap = [] {
+  static const double env_gb = [] {
     const char *s = std::getenv("TEHMM_DEVICE_POOL_GB");
-    const double gb = s ? std::atof(s) : 48.0;
-    return gb > 0.0 ? (size_t)(gb * 1073741824.0) : (size_t)0;
+    return s ? std::atof(s) : -1.0;
   }();
+  if (env_gb == 0.0) return 0;
+  if (env_gb > 0.0) return (size_t)(env_gb * 1073741824.0);
+  const int d = dev_current();
+  DevPool &dp = dev_pool();
+  {
+    std::lock_guard<std::mutex> lk(dp.mu);
+    if ((size_t)d < dp.cap.size() && dp.cap[(size_t)d]) return dp.cap[(size_t)d];
+  }
+  size_t free_b = 0, total_b = 0;
+  size_t cap = (size_t)48 << 30;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) cap = std::min(cap, total_b / 8);
+  else (void)hipGetLastError();
+  std::lock_guard<std::mutex> lk(dp.mu);
+  if (dp.cap.size() <= (size_t)d) dp.cap.resize((size_t)d + 1, 0);
+  dp.cap[(size_t)d] = cap;
   return cap;
 }
 constexpr size_t kDevPoolMin = (size_t)1 << 20, kDevPoolGran = (size_t)2 << 20;
-static size_t dev_pool_trim() {
+// gives back the cached blocks of one device (dev >= 0) or of all devices (dev < 0); the caller's device stays current
+static size_t dev_pool_trim(int dev = -1) {
   DevPool &dp = dev_pool();
-  std::vector<std::pair<void *, size_t>> blocks;
+  std::vector<DevBlock> blocks, keep;
   {
     std::lock_guard<std::mutex> lk(dp.mu);
-    blocks.swap(dp.free_blocks);
-    dp.cached_bytes = 0;
+    for (auto &b : dp.free_blocks) (dev < 0 || b.dev == dev ? blocks : keep).push_back(b);
+    dp.free_blocks.swap(keep);
+    for (auto &b : blocks) dp.cached[(size_t)b.dev] -= b.bytes;
   }
+  if (blocks.empty()) return 0;
+  const int here = dev_current();
+  int cur = here;
   size_t freed = 0;
   for (auto &b : blocks) {
-    (void)hipFree(b.first);
-    freed += b.second;
+    if (b.dev != cur) { (void)hipSetDevice(b.dev); cur = b.dev; }
+    (void)hipFree(b.p);
+    freed += b.bytes;
   }
+  if (cur != here) (void)hipSetDevice(here);
   return freed;
 }
-static size_t dev_pool_cached() {
+static size_t dev_pool_cached(int dev) {
   DevPool &dp = dev_pool();
   std::lock_guard<std::mutex> lk(dp.mu);
-  return dp.cached_bytes;
+  return (size_t)dev < dp.cached.size() ? dp.cached[(size_t)dev] : 0;
 }
 // *block_bytes = size of the block handed out (what dev_free must be told)
 static hipError_t dev_alloc(void **out, size_t bytes, size_t *block_bytes) {
   const bool pooled = bytes >= kDevPoolMin && dev_pool_cap() > 0;
   const size_t need = pooled ? (bytes + kDevPoolGran - 1) / kDevPoolGran * kDevPoolGran : bytes;
+  const int dev = dev_current();
   if (pooled) {
     DevPool &dp = dev_pool();
     std::lock_guard<std::mutex> lk(dp.mu);
     size_t best = SIZE_MAX;
     for (size_t i = 0; i < dp.free_blocks.size(); ++i)
-      if (dp.free_blocks[i].second >= need && dp.free_blocks[i].second <= need + need / 2 &&
-          (best == SIZE_MAX || dp.free_blocks[i].second < dp.free_blocks[best].second))
+      if (dp.free_blocks[i].dev == dev && dp.free_blocks[i].bytes >= need && dp.free_blocks[i].bytes <= need + need / 2 &&
+          (best == SIZE_MAX || dp.free_blocks[i].bytes < dp.free_blocks[best].bytes))
         best = i;
     if (best != SIZE_MAX) {
-      *out = dp.free_blocks[best].first;
-      *block_bytes = dp.free_blocks[best].second;
-      dp.cached_bytes -= dp.free_blocks[best].second;
+      *out = dp.free_blocks[best].p;
+      *block_bytes = dp.free_blocks[best].bytes;
+      dp.cached[(size_t)dev] -= dp.free_blocks[best].bytes;
       dp.free_blocks.erase(dp.free_blocks.begin() + (long)best);
       return hipSuccess;
     }
   }
   hipError_t e = hipMalloc(out, need);
-  if (e != hipSuccess && dev_pool_cached() > 0) {
+  if (e != hipSuccess && dev_pool_cached(dev) > 0) {
     (void)hipGetLastError();
-    (void)dev_pool_trim();
+    (void)dev_pool_trim(dev);
     e = hipMalloc(out, need);
   }
   *block_bytes = e == hipSuccess ? need : 0;
   return e;
 }
-static void dev_free(void *p, size_t block_bytes) {
+// dev = the device the block was allocated on (DBuf records it)
+static void dev_free(void *p, size_t block_bytes, int dev) {
   if (!p) return;
+  const int here = dev_current();
+  if (dev != here) (void)hipSetDevice(dev);
+  bool kept = false;
   if (block_bytes >= kDevPoolMin && dev_pool_cap() > 0) {
-    (void)hipDeviceSynchronize();             // what hipFree would do: nothing on the device still uses the block
+    (void)hipDeviceSynchronize();             // what hipFree would do: nothing on the block's device still uses it
+    const size_t cap = dev_pool_cap();
     DevPool &dp = dev_pool();
     std::lock_guard<std::mutex> lk(dp.mu);
-    if (dp.cached_bytes + block_bytes <= dev_pool_cap()) {
-      dp.free_blocks.emplace_back(p, block_bytes);
-      dp.cached_bytes += block_bytes;
-      return;
+    if (dp.cached.size() <= (size_t)dev) dp.cached.resize((size_t)dev + 1, 0);
+    if (dp.cached[(size_t)dev] + block_bytes <= cap) {
+      dp.free_blocks.push_back({p, block_bytes, dev});
+      dp.cached[(size_t)dev] += block_bytes;
+      kept = true;
     }
   }
-  (void)hipFree(p);
+  if (!kept) (void)hipFree(p);
+  if (dev != here) (void)hipSetDevice(here);
 }
-// free device memory as the workspace decisions should see it: what the driver reports plus what the pool holds
+// free device memory as the workspace decisions should see it: what the driver reports plus what the current device's
+// pool holds (the workspaces these decisions are about are the pool's own clientele: a batch of the same shape takes
+// the cached blocks back one for one, and an allocation that does not fit empties the cache before it fails)
 static hipError_t dev_mem_info(size_t *free_b, size_t *total_b) {
   hipError_t e = hipMemGetInfo(free_b, total_b);
-  if (e == hipSuccess) *free_b += dev_pool_cached();
+  if (e == hipSuccess) *free_b += dev_pool_cached(dev_current());
   return e;
 }
 
@@ -142,12 +188,13 @@ struct DBuf {
   T *p = nullptr;
   size_t n = 0;
   size_t block = 0;            // bytes of the device block behind p (dev_alloc)
+  int dev = 0;                 // device the block lives on
   DBuf() = default;
   DBuf(const DBuf &) = delete;
   DBuf &operator=(const DBuf &) = delete;
   ~DBuf() { release(); }
   void release() {
-    if (p) dev_free(p, block);
+    if (p) dev_free(p, block, dev);
     p = nullptr;
     n = 0;
     cap = 0;
@@ -163,6 +210,7 @@ struct DBuf {
     if (e != hipSuccess) return e;
     p = (T *)q;
     block = blk;
+    dev = dev_current();
     return hipSuccess;
   }
   hipError_t upload(const T *h, size_t count) {
@@ -1305,6 +1353,29 @@ static void launch_vit_lane(tehmm_batch *b, const tehmm_model *m, const Interval
   lw.hs_vi = vi;
   (void)lw.d_vc.fill_async(&lw.hs_vc, 1, st);
   (void)lw.d_vi.fill_async(&lw.hs_vi, 1, st);
+  // round 4: the outputs of a step split over the three waves of a workgroup (tehmm_lane3.hip.h); TEHMM_P2_SPLIT=0
+  // keeps the one-wave kernel (which also serves the smallest models)
+  if constexpr (NT >= 12) {
+    static const bool split = !(std::getenv("TEHMM_P2_SPLIT") && std::atoi(std::getenv("TEHMM_P2_SPLIT")) == 0);
+    if (quant && split) {
+      constexpr int NW = TEHMM_P2_NW;
+      const size_t lds = Lane3Geom<NT, NW>::LDS_BYTES;
+      if constexpr (NT <= TEHMM_RATIO_LANE_MAX) if (ratio) {
+        allow_lds(k_vit_lane3<NT, NW, true>, lds);
+        hipLaunchKernelGGL((k_vit_lane3<NT, NW, true>), dim3(n_work), dim3(64 * NW), lds, st, iv, lg,
+                           (const VitChunks *)lw.d_vc.p, (const VitItems *)lw.d_vi.p, m->N, Wu, (const int *)lw.wk_g.p,
+                           (const int *)lw.wk_e.p, n_work, (const double *)lw.qtabs.p, e0, (const double *)lw.B.p, b->tb.p,
+                           (const double *)b->ratios.p, (const int *)lw.wk_items.p);
+        return;
+      }
+      allow_lds(k_vit_lane3<NT, NW, false>, lds);
+      hipLaunchKernelGGL((k_vit_lane3<NT, NW, false>), dim3(n_work), dim3(64 * NW), lds, st, iv, lg,
+                         (const VitChunks *)lw.d_vc.p, (const VitItems *)lw.d_vi.p, m->N, Wu, (const int *)lw.wk_g.p,
+                         (const int *)lw.wk_e.p, n_work, (const double *)lw.qtabs.p, e0, (const double *)lw.B.p, b->tb.p,
+                         (const double *)nullptr, (const int *)lw.wk_items.p);
+      return;
+    }
+  }
   const dim3 grid((n_work + 3) / 4);
   if constexpr (NT <= TEHMM_RATIO_LANE_MAX) if (quant && ratio) {
     hipLaunchKernelGGL((k_vit_lane<NT, true, true>), grid, dim3(256), 0, st, iv, lg, (const VitChunks *)lw.d_vc.p,
@@ -2437,7 +2508,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       if (emin <= emax) {
         const size_t tsz = quantised_table_size(m, ratio);
         std::vector<double> &qt = lw.hs_qt;
-        qt.resize((size_t)(emax - emin + 1) * tsz);
+        qt.assign((size_t)(emax - emin + 1) * tsz + 64, 0.0);      // (+ one block of padding: k_vit_lane3's prefetch)
         std::vector<char> eok((size_t)(emax - emin + 1), 1);
         for (int e = emin; e <= emax; ++e)
           eok[(size_t)(e - emin)] = ratio ? quantised_table_ratio(m, e, qt.data() + (size_t)(e - emin) * tsz)

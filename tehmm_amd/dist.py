@@ -3,9 +3,10 @@
 The reference's only parallelism is independent per-chromosome worker processes whose outputs are
 concatenated (bin/teHmmEval.py:312-383), and a serial "+=" of sufficient statistics over sequences
 (basehmm.py:507-522, hmm.py:545-574).  Here:
-  * evaluation (Viterbi / posterior): intervals are LPT-sharded by length, every rank evaluates its
-    own shard on its own GPU -- no collective on the data path; an optional gather brings the
-    per-interval log-probabilities / paths to every rank;
+  * evaluation (Viterbi / posterior): EVERY rank passes the same global interval list (checked: check_same_lengths),
+    the list is LPT-sharded by length here, every rank evaluates its own shard on its own GPU -- no collective on
+    the data path; an optional gather brings the per-interval log-probabilities, the uint8 paths and the
+    per-position posterior results (masked sums or full rows: gather_rows) to every rank;
   * training: each rank's E-step statistics are packed into ONE fp64 buffer
     [nobs, logprob, start[N], trans[N,N], obs[K,N,S]] and summed with a single all-reduce per EM
     iteration (RCCL over xGMI with the "nccl" backend; "gloo" on CPU for tests).  The summation order
@@ -115,6 +116,34 @@ def all_agree(flag):
     return bool(int(t.item()))
 
 
+def check_same_lengths(lengths, what="table list"):
+    """Every rank must pass the SAME global interval list to the sharding entry points (they cut it with lpt_shard
+    themselves); a caller that passes per-rank shards would silently train on 1/world of each.  One all-reduce (MIN and
+    MAX of the count and of a hash of the length vector, as MAX of v and of -v); raises ValueError on EVERY rank."""
+    import torch
+    dist = _dist()
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    lengths = np.ascontiguousarray(np.asarray(lengths, dtype=np.int64))
+    import zlib
+    h = zlib.crc32(lengths.tobytes()) & 0x7fffffff
+    v = np.asarray([len(lengths), h, int(lengths.sum()) & 0x7fffffffffff], dtype=np.int64)
+    t = torch.from_numpy(np.concatenate([v, -v])).to(_device_for_backend())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t = t.cpu().numpy()
+    if not np.array_equal(t[:3], -t[3:]):
+        raise ValueError("tehmm_amd.dist: the ranks passed different %ss (count / lengths differ); every rank passes the "
+                         "full global list and the library shards it" % what)
+
+
+def _raise_together(msg):
+    """Collective-safe validation: `msg` is this rank's error (or None); if ANY rank has one, every rank raises, so
+    that nobody is left waiting in the next collective."""
+    ok = all_agree(msg is None)
+    if not ok:
+        raise ValueError(msg if msg is not None else "tehmm_amd.dist: another rank failed its argument check")
+
+
 def gather_interval_scalars(local_idx, local_values, n_total, lengths=None):
     """All ranks get the full per-interval array (e.g. Viterbi log-probs) of a sharded batch: one
     all-gather of (index, value) pairs padded to the largest shard."""
@@ -158,12 +187,21 @@ def gather_paths(local_idx, local_paths, lengths):
     world = dist.get_world_size()
     dev = _device_for_backend()
     local_idx = np.asarray(local_idx, dtype=np.int64)
+    err = None
+    cat = np.zeros(0, dtype=np.int64)
     if len(local_idx) != len(local_paths):
-        raise ValueError("gather_paths: %d indices for %d paths" % (len(local_idx), len(local_paths)))
-    for i, p in zip(local_idx, local_paths):
-        if len(p) != int(lengths[i]):
-            raise ValueError("gather_paths: path of interval %d has %d states, the interval %d rows"
-                             % (int(i), len(p), int(lengths[i])))
+        err = "gather_paths: %d indices for %d paths" % (len(local_idx), len(local_paths))
+    else:
+        for i, p in zip(local_idx, local_paths):
+            if len(p) != int(lengths[i]):
+                err = ("gather_paths: path of interval %d has %d states, the interval %d rows"
+                       % (int(i), len(p), int(lengths[i])))
+                break
+    if err is None and len(local_paths):
+        cat = np.concatenate([np.asarray(p) for p in local_paths]) if len(local_paths) > 1 else np.asarray(local_paths[0])
+        if cat.size and (int(cat.max()) >= 256 or int(cat.min()) < 0):
+            err = "gather_paths: states must fit a byte"
+    _raise_together(err)              # (every rank raises or none: no rank is left alone in the collectives below)
     # which intervals every rank holds, in the order it sends them (any sharding, not only lpt_shard's)
     cnt = torch.tensor([len(local_idx)], dtype=torch.int64, device=dev)
     cmax = cnt.clone()
@@ -178,11 +216,7 @@ def gather_paths(local_idx, local_paths, lengths):
     sizes = [int(lengths[h[h >= 0]].sum()) for h in held]
     cap = max(max(sizes), 1)
     mine = np.zeros(cap, dtype=np.uint8)
-    if len(local_paths):
-        cat = np.concatenate([np.asarray(p) for p in local_paths]) if len(local_paths) > 1 else np.asarray(local_paths[0])
-        if cat.size and (int(cat.max()) >= 256 or int(cat.min()) < 0):
-            raise ValueError("gather_paths: states must fit a byte")
-        mine[:cat.size] = cat.astype(np.uint8)
+    mine[:cat.size] = cat.astype(np.uint8)
     send = torch.from_numpy(mine).to(dev)
     recv = torch.empty(world * cap, dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(recv, send)
@@ -191,10 +225,82 @@ def gather_paths(local_idx, local_paths, lengths):
     for r in range(world):
         o = 0
         for i in held[r][held[r] >= 0]:
-            if out[int(i)] is not None:
+            if out[int(i)] is not None:     # (every rank sees the same `held`: all of them raise)
                 raise ValueError("gather_paths: interval %d is held by more than one rank" % int(i))
             out[int(i)] = recv[r, o:o + int(lengths[i])].astype(np.int64)
             o += int(lengths[i])
+    return out
+
+
+def gather_rows(local_idx, local_rows, lengths, width=None):
+    """Gather of per-POSITION float64 results of the sharded intervals to every rank, in global interval order:
+    `local_rows[j]` is an array [lengths[local_idx[j]]] or [lengths[..], width] -- the masked posterior sums teHmmEval
+    writes with --pd (8 bytes per position: the natural payload, tehmm_batch_posterior_masksum) or the full posterior
+    rows [T, N] (bin/teHmmEval.py:270-272; its per-chromosome workers' outputs are concatenated, :312-383).  ONE
+    all-gather of the index lists and ONE of the concatenated rows padded to the largest shard."""
+    import torch
+    dist = _dist()
+    lengths = np.asarray(lengths, dtype=np.int64)
+    n = len(lengths)
+    local_idx = np.asarray(local_idx, dtype=np.int64)
+    rows = [np.asarray(r, dtype=np.float64) for r in local_rows]
+    if width is None and rows:
+        width = 0 if rows[0].ndim == 1 else int(rows[0].shape[1])
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        out = [None] * n
+        for i, r in zip(local_idx, rows):
+            out[int(i)] = r
+        return out
+    world = dist.get_world_size()
+    dev = _device_for_backend()
+    # the row width must be the same everywhere; a rank with an empty shard learns it from the others
+    NONE = -(1 << 40)
+    wt = torch.tensor([width, -width] if width is not None else [NONE, NONE], dtype=torch.int64, device=dev)
+    dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+    wmax, wmin = int(wt[0].item()), -int(wt[1].item())
+    err = None
+    if width is None:
+        width = max(wmax, 0)
+    elif wmax != width or wmin != width:
+        err = "gather_rows: the ranks hold row blocks of different widths (%d here)" % width
+    if err is None and len(local_idx) != len(rows):
+        err = "gather_rows: %d indices for %d row blocks" % (len(local_idx), len(rows))
+    if err is None:
+        for i, r in zip(local_idx, rows):
+            if r.shape[0] != int(lengths[i]) or (width and (r.ndim != 2 or r.shape[1] != width)) or (not width and r.ndim != 1):
+                err = "gather_rows: block of interval %d has shape %s, expected %d rows x %d" % (
+                    int(i), r.shape, int(lengths[i]), max(width, 1))
+                break
+    _raise_together(err)
+    cnt = torch.tensor([len(local_idx)], dtype=torch.int64, device=dev)
+    cmax = cnt.clone()
+    dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+    icap = max(int(cmax.item()), 1)
+    ibuf = np.full(icap, -1, dtype=np.int64)
+    ibuf[:len(local_idx)] = local_idx
+    irecv = torch.empty(world * icap, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(irecv, torch.from_numpy(ibuf).to(dev))
+    held = irecv.cpu().numpy().reshape(world, icap)
+    per = max(width, 1)
+    sizes = [int(lengths[h[h >= 0]].sum()) * per for h in held]
+    cap = max(max(sizes), 1)
+    mine = np.zeros(cap, dtype=np.float64)
+    if rows:
+        cat = np.concatenate([r.reshape(-1) for r in rows])
+        mine[:cat.size] = cat
+    recv = torch.empty(world * cap, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(recv, torch.from_numpy(mine).to(dev))
+    recv = recv.cpu().numpy().reshape(world, cap)
+    out = [None] * n
+    for r in range(world):
+        o = 0
+        for i in held[r][held[r] >= 0]:
+            if out[int(i)] is not None:
+                raise ValueError("gather_rows: interval %d is held by more than one rank" % int(i))
+            m = int(lengths[i]) * per
+            blk = recv[r, o:o + m].copy()
+            out[int(i)] = blk.reshape(int(lengths[i]), width) if width else blk
+            o += m
     return out
 
 
@@ -211,11 +317,18 @@ class ShardedEvaluator(object):
         world = dist.get_world_size() if dist.is_initialized() else 1
         rank = dist.get_rank() if dist.is_initialized() else 0
         lengths = [len(t) for t in tables]
+        check_same_lengths(lengths, "interval list")
         mine = lpt_shard(lengths, world)[rank]
         res = self.compute([tables[i] for i in mine])
         if not gather or world == 1:
             return mine, res
         out = {}
+        # per-position posterior results (north_star: "gather of per-interval posteriors and Viterbi paths"): the masked
+        # sums of the --pd column (8 B per row) and / or the full rows, whatever `compute` returned
+        if res.get("posterior_masksum") is not None:
+            out["posterior_masksum"] = gather_rows(mine, res["posterior_masksum"], lengths, width=0)
+        if res.get("posteriors") is not None:
+            out["posteriors"] = gather_rows(mine, res["posteriors"], lengths)
         if res.get("viterbi_logprob") is not None:
             out["viterbi_logprob"] = gather_interval_scalars(mine, res["viterbi_logprob"], len(tables))
         if res.get("forward_logprob") is not None:
@@ -231,6 +344,7 @@ def sharded_estep(tables, estep_fn, empty_stats):
     dist = _dist()
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
+    check_same_lengths([len(t) for t in tables], "training table list")
     mine = lpt_shard([len(t) for t in tables], world)[rank]
     stats = empty_stats()
     if rank != 0:

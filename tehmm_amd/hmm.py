@@ -388,8 +388,15 @@ class MultitrackHmm(BaseHMM):
         self.current_iteration += 1
         self.validate()
 
-    def fit(self, obs, **kwargs):
+    def fit(self, obs, shard_lengths=None, **kwargs):
+        """basehmm.py:475-541.  shard_lengths (multi-GPU only): the row counts of ALL training tables in global order;
+        `obs` may then hold None for the tables this rank does not own (dist.lpt_shard(shard_lengths, world)[rank]),
+        so that a rank loads only its own shard of an hg19-sized training set."""
         self.current_iteration = 1
+        if shard_lengths is not None:
+            if len(shard_lengths) != len(obs):
+                raise ValueError("fit: shard_lengths must name every table of the global list")
+            return self._fit_device(obs, lengths=[int(x) for x in shard_lengths])
         if self._can_fit_on_device(obs):
             return self._fit_device(obs)
         return BaseHMM.fit(self, obs, **kwargs)
@@ -410,7 +417,7 @@ class MultitrackHmm(BaseHMM):
         #  in the per-iteration all-reduce)
         return em.zeroAsMissingData is True and self.n_components < 64 and len(obs) > 0 and self._can_fuse(obs)
 
-    def _fit_device(self, tables):
+    def _fit_device(self, tables, lengths=None):
         """BaseHMM.fit (basehmm.py:475-541) with the observations, the sufficient statistics and the
         parameters resident on the device: per iteration one fused E-step per batch (statistics ADDED
         into one flat device buffer), the convergence test on the returned log-likelihood, and
@@ -427,12 +434,19 @@ class MultitrackHmm(BaseHMM):
         from .engine import DeviceStats, HipBatch
         if self.algorithm not in ("viterbi", "map"):
             self._algorithm = "viterbi"
-        self._init(tables, self.init_params)
         world, rank = tdist.world_rank()
         n_seq = len(tables)
+        if lengths is None:
+            lengths = [len(t) for t in tables]
+        # every rank must hold the same GLOBAL list (or its lengths): a caller that passes per-rank shards would train
+        # on 1 / world of each shard with colliding sequence indices -- refused on every rank alike
+        tdist.check_same_lengths(lengths, "training table list")
         mine = list(range(n_seq))
         if world > 1:
-            mine = [int(i) for i in tdist.lpt_shard([len(t) for t in tables], world)[rank]]
+            mine = [int(i) for i in tdist.lpt_shard(lengths, world)[rank]]
+        if any(tables[i] is None for i in mine):
+            raise ValueError("fit: a table of this rank's shard is None (shard = dist.lpt_shard(shard_lengths, world)[rank])")
+        self._init([tables[i] for i in mine] if any(t is None for t in tables) else tables, self.init_params)
         arrays = {i: (tables[i].getNumPyArray() if isinstance(tables[i], TrackTable)
                       else np.ascontiguousarray(tables[i])) for i in mine}
         ratios = {i: self.emissionModel.getSegmentRatios(tables[i]) for i in mine}

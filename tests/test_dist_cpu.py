@@ -114,3 +114,69 @@ def test_world2_sharded_eval_and_estep_match_serial():
         assert_allclose(stats["start"], serial["start"], rtol=1e-12)
         assert_allclose(stats["trans"], serial["trans"], rtol=1e-12)
         assert_allclose(stats["obs"], serial["obs"] + 0.25, rtol=1e-12)
+
+
+def _worker_rows(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tehmm_amd.dist import ShardedEvaluator, check_same_lengths, gather_rows
+        lens = [40, 1, 17, 0, 23]
+        rs = np.random.RandomState(7)
+        full = [rs.rand(L, 6) for L in lens]                 # "posterior rows" [T, N]
+        msum = [f[:, :2].sum(axis=1) for f in full]          # the --pd column: masked sum per position
+
+        def compute(sub_idx_tables):
+            # (tables here are just index arrays of the right length: the compute looks its rows up)
+            ids = [int(t[0]) if len(t) else 3 for t in sub_idx_tables]
+            return {"posteriors": [full[i] for i in ids], "posterior_masksum": [msum[i] for i in ids],
+                    "viterbi_logprob": [float(i) for i in ids]}
+        tables = [np.full(L, i, dtype=np.int64) for i, L in enumerate(lens)]
+        mine, res = ShardedEvaluator(compute).run(tables)
+        # an empty shard: rank 1 of 2 holds nothing -> it learns the row width from rank 0
+        only0 = gather_rows([0, 2] if rank == 0 else [], [full[0], full[2]] if rank == 0 else [], lens)
+        # different lists on the ranks are refused on EVERY rank
+        try:
+            check_same_lengths(lens if rank == 0 else lens[:-1])
+            refused = False
+        except ValueError:
+            refused = True
+        # a bad block on ONE rank raises on both (no rank left in a collective)
+        try:
+            gather_rows([1], [np.zeros((2, 6))] if rank == 0 else [np.zeros((1, 6))], lens)
+            together = False
+        except ValueError:
+            together = True
+        q.put((rank, res, only0, refused, together))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world2_posterior_gather_and_collective_checks():
+    """north_star's "gather of per-interval posteriors": masked sums (8 B per row) and full rows through
+    ShardedEvaluator; list-consistency check; validation errors raise on every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_rows, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    lens = [40, 1, 17, 0, 23]
+    rs = np.random.RandomState(7)
+    full = [rs.rand(L, 6) for L in lens]
+    for rank, res, only0, refused, together in got:
+        assert refused and together
+        for i, L in enumerate(lens):
+            assert_array_equal(res["posteriors"][i], full[i])
+            assert_array_equal(res["posterior_masksum"][i], full[i][:, :2].sum(axis=1))
+        assert_array_equal(only0[0], full[0])
+        assert_array_equal(only0[2], full[2])
+        assert only0[1] is None and only0[4] is None

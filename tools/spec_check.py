@@ -42,4 +42,4 @@ def main():
     return bad
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(int(main()))
