@@ -197,8 +197,34 @@ def time_eval(hm, hb, torch, steps=1, **kw):
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(steps):
-        hm.eval(hb, **kw)
+        time_eval.last = hm.eval(hb, **kw)
     return (time.perf_counter() - t1) / steps
+
+
+def verify_one(model, hb, obs, offs, res, ratios=None, max_len=260_000, n_threads=2):
+    """Oracle check of ONE interval of an `extra` workload (the shortest; skipped when longer than max_len): the results
+    of the last evaluation against the oracle's decode / score_samples flow (decode: ratios on the transitions only,
+    score_samples: none -- basehmm.py:327-329, 261-273).  Returns a dict for the extra's record."""
+    from oracle import oracle
+    lens = np.diff(offs)
+    i = int(np.argmin(lens))
+    if lens[i] > max_len:
+        return {"verified": None, "note": "shortest interval %d > %d positions: not checked here" % (lens[i], max_len)}
+    a, b = int(offs[i]), int(offs[i + 1])
+    sub = obs[a:b].cpu().numpy()
+    r = None if ratios is None else ratios[a:b].cpu().numpy()
+    t0 = time.perf_counter()
+    ok, worst = True, None
+    if res.get("viterbi_logprob") is not None:
+        vlp, path = oracle.decode(sub, model.log_probs, model.log_startprob, model.log_transmat, 1.0, r)
+        ok &= bool(np.array_equal(hb.paths(a, b), path)) and bool(res["viterbi_logprob"][i] == vlp)
+    if res.get("forward_logprob") is not None:
+        flp, post = oracle.score_samples(sub, model.log_probs, model.log_startprob, model.log_transmat, 1.0)
+        got = hb.posteriors(model.n_states, a, b)
+        worst = float(np.max(np.abs(got - post) / post))
+        ok &= worst <= 1e-6 and abs(res["forward_logprob"][i] - flp) <= 1e-6 * abs(flp)
+    return {"verified": bool(ok), "verified_interval": int(lens[i]), "posterior_max_rel_err": worst,
+            "verify_s": round(time.perf_counter() - t0, 2)}
 
 
 def run_eval(args, rank, world, local_rank):
@@ -298,7 +324,8 @@ def run_eval(args, rank, world, local_rank):
                 "forward_pass": 2 * N * N, "backward_posterior_pass": 2 * N * N}
         traffic = None
         stage_hbm = None
-        tpath = next((p for p in (os.path.join(ROOT, "profiles", "r03_traffic.json"),
+        tpath = next((p for p in (os.path.join(ROOT, "profiles", "r04_traffic.json"),
+                                  os.path.join(ROOT, "profiles", "r03_traffic.json"),
                                   os.path.join(ROOT, "profiles", "r02_traffic.json"),
                                   os.path.join(ROOT, "profiles", "r01_traffic.json")) if os.path.exists(p)), None)
         if tpath:     # HBM bytes per position measured with rocprofv3 --pmc (see file)
@@ -414,7 +441,9 @@ def extras(args, model, hm, hb, obs, offs, lens, device, torch, mk_model):
     obs1 = gen_obs_torch(model, one, seed=99, device=device)
     hb1 = HipBatch(obs1.data_ptr(), np.asarray([0, one[0]], dtype=np.int64), device_ptrs=True, K=K)
     d1 = time_eval(hm, hb1, torch, viterbi=True, posterior=True)
-    ex["config2_single_10Mb_interval"] = rate(one[0], d1, kernel_ms=hb1.timing())
+    ex["config2_single_10Mb_interval"] = rate(one[0], d1, kernel_ms=hb1.timing(),
+                                              note="checked bit for bit against the oracle at this size by "
+                                                   "tests/test_gpu_r2.py::test_config2_full_size_vs_oracle (100 s of CPU)")
     d1v = time_eval(hm, hb1, torch, viterbi=True, posterior=False)
     ex["config2_single_10Mb_interval_viterbi_only"] = rate(one[0], d1v)
     hb1.close()
@@ -434,7 +463,8 @@ def extras(args, model, hm, hb, obs, offs, lens, device, torch, mk_model):
         hmv = mk_model(mdl)
         hbv = HipBatch(ob.data_ptr(), o3, device_ptrs=True, K=K)
         d = time_eval(hmv, hbv, torch, viterbi=True, posterior=True)
-        ex["model_" + tag] = rate(n3, d, positions=n3, kernel_ms=hbv.timing())
+        ex["model_" + tag] = rate(n3, d, positions=n3, kernel_ms=hbv.timing(),
+                                  **({} if args.no_verify else verify_one(mdl, hbv, ob, o3, time_eval.last)))
         hbv.close()
         hmv.close()
         del ob
@@ -467,7 +497,8 @@ def extras(args, model, hm, hb, obs, offs, lens, device, torch, mk_model):
     ratios = (seglen / 100.0).contiguous()
     hbr = HipBatch(ob.data_ptr(), o3, ratios=ratios.data_ptr(), device_ptrs=True, K=K)
     d = time_eval(hm, hbr, torch, viterbi=True, posterior=True, use_ratios=True)
-    ex["decode_with_segment_ratios"] = rate(n3, d, positions=n3, kernel_ms=hbr.timing())
+    ex["decode_with_segment_ratios"] = rate(n3, d, positions=n3, kernel_ms=hbr.timing(),
+                                            **({} if args.no_verify else verify_one(model, hbr, ob, o3, time_eval.last, ratios)))
     hbr.close()
     del ob, ratios, seglen
 
@@ -486,6 +517,10 @@ def extras(args, model, hm, hb, obs, offs, lens, device, torch, mk_model):
     hb5 = HipBatch(ob.data_ptr(), o5, ratios=r5.data_ptr(), device_ptrs=True, K=K)
     d = time_eval(hm5, hb5, torch, viterbi=True, posterior=True, use_ratios=True)
     ex["config5_100_states_segmented"] = rate(int(o5[-1]), d, positions=int(o5[-1]), kernel_ms=hb5.timing())
+    if not args.no_verify:        # one 100 kb interval of this workload against the oracle (N = 100, ratios)
+        v5 = verify_one(m5, hb5, ob, o5, time_eval.last, r5, n_threads=2)
+        ex["config5_100_states_segmented"].update(v5)
+        ex["config5_verified"] = v5["verified"]
     # the two halves: the posterior runs item-parallel on the matrix cores, the exact Viterbi with segment ratios
     # chunk-parallel with an exact chain that follows the quantised pass (tehmm_wide.hip.h)
     d = time_eval(hm5, hb5, torch, viterbi=False, posterior=True, use_ratios=True)
@@ -497,11 +532,38 @@ def extras(args, model, hm, hb, obs, offs, lens, device, torch, mk_model):
     del ob, r5
 
     # (5) BASELINE configs[3] shape on one GPU: Baum-Welch iterations, 35 states, 12 tracks, 100 kb chunks
-    ex["config4_em_iteration"] = em_iterations(50.0, 2, device, torch, None)
+    ex["config4_em_iteration"] = em_iterations(50.0, 2, device, torch, None, verify=not args.no_verify)
     return ex
 
 
-def em_iterations(mb, n_iter, device, torch, dist):
+def verify_estep(start, ob, o4, n_chunks=4):
+    """The fused E-step of the FIRST n_chunks training chunks against the oracle's per-sequence E-step (hmm.py:545-574)
+    from the same start model: statistics within 1e-6 (observed error on the record)."""
+    from oracle import oracle
+    from tehmm_amd.engine import HipBatch, HipModel
+    n_chunks = min(n_chunks, len(o4) - 1)
+    sub = ob[:int(o4[n_chunks])].cpu().numpy()
+    so = np.asarray(o4[:n_chunks + 1], dtype=np.int64)
+    K, N, S = start.log_probs.shape
+    hm = HipModel(start.log_transmat, start.log_startprob, start.log_probs, symbols_per_track=start.symbols_per_track)
+    hb = HipBatch(sub, so)
+    st0, tr, ob_st = np.zeros(N), np.zeros((N, N)), np.zeros((K, N, S))
+    lp = hm.estep(hb, False, st0, tr, ob_st)
+    hb.close()
+    hm.close()
+    t0 = time.perf_counter()
+    ref = oracle.estep([sub[int(so[i]):int(so[i + 1])] for i in range(n_chunks)], start.log_probs, start.log_startprob,
+                       start.log_transmat, 1.0, None)
+
+    def rel(a, b, floor):
+        return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
+    worst = max(rel(st0, ref["start"], 1e-12), rel(tr, ref["trans"], 1e-6), rel(ob_st, ref["obs"], 1e-6))
+    ok = worst <= 1e-6 and abs(lp - ref["logprob"]) <= 1e-9 * abs(ref["logprob"])
+    return {"verified": bool(ok), "verified_chunks": int(n_chunks), "statistics_max_rel_err": worst,
+            "verify_s": round(time.perf_counter() - t0, 2)}
+
+
+def em_iterations(mb, n_iter, device, torch, dist, verify=False):
     """Baum-Welch iterations on the config-4 shape: per iteration one fused E-step over the rank's 100 kb
     chunks (statistics left on the device), ONE all-reduce of the flat statistics buffer, device M-step."""
     from tehmm_amd import synth
@@ -513,6 +575,7 @@ def em_iterations(mb, n_iter, device, torch, dist):
     ob = gen_obs_torch(m4, l4, seed=41, device=device)
     # start EM from a perturbed model so that the iterations do real work
     start = synth.make_model(N_STATES, synth.CONFIG4_SYMBOLS, synth.CONFIG4_GAUSSIAN, seed=7)
+    verdict = verify_estep(start, ob, o4) if verify else {}
     hm4 = HipModel(start.log_transmat, start.log_startprob, start.log_probs, symbols_per_track=start.symbols_per_track)
     hb4 = HipBatch(ob.data_ptr(), o4, device_ptrs=True, K=m4.n_tracks)
     st = DeviceStats(hm4)
@@ -542,9 +605,20 @@ def em_iterations(mb, n_iter, device, torch, dist):
     st.close()
     hm4.close()
     del ob
-    return {"value": float(n) / d, "unit": "positions/s per EM iteration", "ms_per_iteration": d * 1e3,
-            "positions": n, "chunks": int(n_chunks), "logprob_per_iteration": lps, "estep_stage_ms": stage_ms,
-            "alg_bytes_per_position": m4.n_tracks, "hbm_GBps_algorithmic": m4.n_tracks * float(n) / d / 1e9}
+    out = {"value": float(n) / d, "unit": "positions/s per EM iteration", "ms_per_iteration": d * 1e3,
+           "positions": n, "chunks": int(n_chunks), "logprob_per_iteration": lps, "estep_stage_ms": stage_ms,
+           "alg_bytes_per_position": m4.n_tracks, "hbm_GBps_algorithmic": m4.n_tracks * float(n) / d / 1e9}
+    out.update(verdict)
+    return out
+
+
+def estep_traffic(positions):
+    """Measured HBM bytes of one EM iteration (per-position figure of profiles/r04_estep_traffic.json x positions)."""
+    p = os.path.join(ROOT, "profiles", "r04_estep_traffic.json")
+    if not os.path.exists(p):
+        return None
+    tj = json.load(open(p)).get("hbm_bytes_per_position", {})
+    return tj["total"] * float(positions) if "total" in tj else None
 
 
 def run_estep(args, rank, world, local_rank):
@@ -558,7 +632,7 @@ def run_estep(args, rank, world, local_rank):
     if use_dist:
         init_dist(dist, device)
     mb = 200.0 if args.mb is None else args.mb
-    r = em_iterations(mb, args.steps, device, torch, dist if use_dist else None)
+    r = em_iterations(mb, args.steps, device, torch, dist if use_dist else None, verify=(rank == 0 and not args.no_verify))
     if rank == 0:
         d = r["ms_per_iteration"] * 1e-3
         value = r["positions"] * world / d
@@ -568,6 +642,10 @@ def run_estep(args, rank, world, local_rank):
                "dtype": "f64", "data": "synthetic",
                "config": {"workload": "teHmmTrain E-step + all-reduce + M-step, 35 states, 12 tracks (10 multinomial "
                                       "+ 2 gaussian), %.0f Mb per GPU in 100 kb chunks (config-4 geometry)" % mb,
+                          "arithmetic": "f64 arithmetic in the passes and all sums; the alpha', gamma and wz rows between "
+                                        "the passes and the reductions are f32, the one-hot histogram products three "
+                                        "exact bf16 pieces per f32 gamma (statistics agree with the reference to ~1e-7, "
+                                        "bar 1e-6); sums reproducible run to run (per-writer partials, ordered fold)",
                           "positions_per_gpu": r["positions"], "intervals_per_gpu": r["chunks"],
                           "parallelism": "chunks sharded over %d GPU(s), one all-reduce of %s per iteration"
                                          % (world, "the packed statistics")},
@@ -575,12 +653,17 @@ def run_estep(args, rank, world, local_rank):
                             "achieved": r["alg_bytes_per_position"] * r["positions"] / d / 1e9,
                             "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": r["alg_bytes_per_position"] * r["positions"] / d / 1e9 / HBM_PEAK_GBPS,
-                            "traffic": None,
+                            "traffic": estep_traffic(r["positions"]),
+                            "traffic_source": "profiles/r04_estep_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                                              if estep_traffic(r["positions"]) is not None else None,
                             # what really binds: fp64 matrix + vector issue; forward + backward + xi = 3 x 2 N^2 flop
                             "f64": {"achieved": 6.0 * N_STATES * N_STATES * r["positions"] / d / 1e12,
                                     "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s"}},
                "estep_stage_ms": r["estep_stage_ms"],
                "logprob_per_iteration": r["logprob_per_iteration"]}
+        for k in ("verified", "verified_chunks", "statistics_max_rel_err", "verify_s"):
+            if k in r:
+                out[k] = r[k]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_estep()
         print(json.dumps(out))

@@ -136,18 +136,25 @@ def trim_pools():
 
 
 def pinned_empty(shape, dtype):
-    """numpy array over pinned host memory (tehmm_host_alloc): D2H copies into it are one DMA."""
+    """numpy array over pinned host memory (tehmm_host_alloc): D2H copies into it are one DMA.  If the pinned
+    allocation fails (a multi-GB request on a host short of lockable memory) the array is ordinary pageable memory:
+    slower transfers, same results."""
     shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
     dt = np.dtype(dtype)
     n = int(np.prod(shape)) if shape else 1
-    blk = _PinnedBlock(n * dt.itemsize)
+    try:
+        blk = _PinnedBlock(n * dt.itemsize)
+    except TeHmmHipError:
+        return np.empty(shape, dtype=dt)
     buf = (ctypes.c_char * max(n * dt.itemsize, 1)).from_address(blk.ptr.value)
     arr = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
     return _PinnedArray(arr, blk)
 
 
 class _PinnedArray(np.ndarray):
-    """ndarray view that owns its pinned block."""
+    """ndarray over a pinned block.  Only the array made by pinned_empty owns the block; views keep it alive through
+    .base, and results COMPUTED from it (ufunc outputs, reductions, copies) are plain ndarrays in ordinary memory --
+    a small result must not keep a multi-GB pinned block alive."""
 
     def __new__(cls, arr, blk):
         obj = arr.view(cls)
@@ -155,7 +162,11 @@ class _PinnedArray(np.ndarray):
         return obj
 
     def __array_finalize__(self, obj):
-        self._blk = getattr(obj, "_blk", None)
+        self._blk = None
+
+    def __array_wrap__(self, out, context=None, return_scalar=False):
+        out = np.asarray(out)
+        return out[()] if return_scalar else out
 
 
 def as_f64(a):

@@ -73,7 +73,14 @@ struct EstepGeom {
   }
 };
 
-__device__ __forceinline__ void estep_atomic_add(double *p, double v) { unsafeAtomicAdd(p, v); }
+// Reproducible sums (round 4).  Rounds 1..3 flushed every persistent workgroup's accumulators into the statistics with
+// floating-point atomics: the order of those additions -- and with it the last bits of every statistic, of the
+// M-step's parameters and of the --maxProb / convergence decisions taken on them -- changed from run to run.  Now
+// every writer (a wave of k_estep_xi, a workgroup of the two histogram kernels) owns one SLOT of a partial buffer
+// and writes its sums there; k_estep_fold_* add the slots in ascending order.  The work of a writer is a fixed
+// function of the batch geometry, so the same input gives the same bits.  The LDS histograms of k_estep_hist_lds are
+// accumulated by eight waves in whatever order they arrive: they are kept as 64-bit FIXED-POINT integers
+// (ds_add_u64 is exact, hence order-free; the scale leaves 62 bits for the largest sum a workgroup can reach).
 
 // What every reduction kernel knows about the 16-item tile a wave works on.
 struct EstepTile {
@@ -110,9 +117,12 @@ __device__ __forceinline__ EstepTile estep_tile(const IntervalTab &iv, const Lan
 template <int NT>
 __global__ __launch_bounds__(256) void k_estep_xi(IntervalTab iv, LaneGeom lg, int N, const float *__restrict__ al32,
                                                   const float *__restrict__ gam32, const float *__restrict__ wz32,
-                                                  double *gC, double *gstart) {
+                                                  double *part /* [4 gridDim.x][NT * NT + NT] */) {
   using G = EstepGeom<NT>;
   constexpr int P = G::P, PQ = G::PQ, NTILE = G::NTILE;
+  double sacc[2 * P];                                              // start statistics of this lane's (item, state quarter)
+#pragma unroll
+  for (int p = 0; p < 2 * P; ++p) sacc[p] = 0.0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int kq = lane >> 4, i16 = lane & 15;
   const int g_pp = (lane & 15) >> 2, g_kq = lane & 3, g_k = lane >> 4;
@@ -131,8 +141,8 @@ __global__ __launch_bounds__(256) void k_estep_xi(IntervalTab iv, LaneGeom lg, i
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const float2 g = gam2[tc.tb2 + kq * 16 + i16 + p * 64];
-        if (kq + 8 * p < N) estep_atomic_add(&gstart[kq + 8 * p], (double)g.x);
-        if (kq + 8 * p + 4 < N) estep_atomic_add(&gstart[kq + 8 * p + 4], (double)g.y);
+        sacc[2 * p] += (double)g.x;
+        sacc[2 * p + 1] += (double)g.y;
       }
     }
     const int64_t gb2 = tc.tb2 + g_kq * 16 + g_k;                  // + (4 q + pp) * 64 + 4 kk, + 256 P per position
@@ -171,6 +181,7 @@ __global__ __launch_bounds__(256) void k_estep_xi(IntervalTab iv, LaneGeom lg, i
     }
   }
   // accumulator (lane, register r) of tile pair (ta, tw) is C[state(ta, 4 r + (lane >> 4))][state(tw, lane & 15)]
+  double *slot = part + (size_t)(blockIdx.x * 4 + wv) * (NT * NT + NT);
 #pragma unroll
   for (int ta = 0; ta < NTILE; ++ta)
 #pragma unroll
@@ -179,8 +190,17 @@ __global__ __launch_bounds__(256) void k_estep_xi(IntervalTab iv, LaneGeom lg, i
       for (int r = 0; r < 4; ++r) {
         const int i = G::state(ta, 4 * r + (lane >> 4)), j = G::state(tw, lane & 15);
         const double v = acc[ta][tw][r];
-        if (i < N && j < N && v != 0.0) estep_atomic_add(&gC[i * NT + j], v);
+        if (i < NT && j < NT) slot[i * NT + j] = (i < N && j < N) ? v : 0.0;       // (every cell, zeros included)
       }
+  // start: the 16 items of the tile lanes, fixed tree; states kq + 8 p (+ 4)
+#pragma unroll
+  for (int p = 0; p < 2 * P; ++p) {
+    double v = sacc[p];
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
+    const int st = kq + 8 * (p >> 1) + 4 * (p & 1);
+    if (i16 == 0 && st < NT) slot[NT * NT + st] = st < N ? v : 0.0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -194,7 +214,7 @@ __global__ __launch_bounds__(256) void k_estep_xi(IntervalTab iv, LaneGeom lg, i
 template <int NT, int RT>
 __device__ __forceinline__ void estep_hist_mfma_run(const IntervalTab &iv, const LaneGeom &lg, const EstepGroups *__restrict__ egp,
                                                     int N, int KP, const uint8_t *__restrict__ obs,
-                                                    const float *__restrict__ gam32, double *gstat, int rt0) {
+                                                    const float *__restrict__ gam32, double *part, int rt0) {
   using G = EstepGeom<NT>;
   constexpr int P = G::P, PQ = G::PQ, NTILE = G::NTILE;
   const int lane = threadIdx.x & 63;
@@ -408,12 +428,13 @@ __device__ __forceinline__ void estep_hist_mfma_run(const IntervalTab &iv, const
 #else
       const int row = (rt0 + r) * 16 + 4 * (lane >> 4) + q;
 #endif
-      const int grow = egp->rt_info[row] < 0 ? -1 : egp->rt_grow[row];
+      // this workgroup's slot: [n_rt * 16 rows][NT]; every cell of the wave's row tiles is written (k_estep_fold_rows
+      // maps the rows to the statistics table and drops the padding rows)
+      double *srow = part + ((size_t)blockIdx.x * (egp->n_rt * 16) + row) * NT;
 #pragma unroll
       for (int tw = 0; tw < NTILE; ++tw) {
         const int j = G::state(tw, lane & 15);
-        const double v = acc[r][tw][q];
-        if (grow >= 0 && j < N && v != 0.0) estep_atomic_add(&gstat[(int64_t)grow * NT + j], v);
+        if (j < NT) srow[j] = j < N ? acc[r][tw][q] : 0.0;
       }
     }
   }
@@ -430,7 +451,7 @@ __device__ __forceinline__ void estep_hist_mfma_run(const IntervalTab &iv, const
 template <int NT>
 __global__ __launch_bounds__(TEHMM_ESTEP_HW * 64) void k_estep_hist_mfma(IntervalTab iv, LaneGeom lg, const EstepGroups *__restrict__ egp,
                                                                        int N, int KP, const uint8_t *__restrict__ obs,
-                                                                       const float *__restrict__ gam32, double *gstat) {
+                                                                       const float *__restrict__ gam32, double *part) {
   constexpr int RTG = EstepGeom<NT>::RTG;
   const int rtg0 = blockIdx.y * RTG;
   const int nrt = min(RTG, egp->n_rt - rtg0);
@@ -438,11 +459,11 @@ __global__ __launch_bounds__(TEHMM_ESTEP_HW * 64) void k_estep_hist_mfma(Interva
   const int wv = threadIdx.x >> 6;
   const int rt0 = rtg0 + wv * rtw;
   const int mine = max(0, min(rtw, nrt - wv * rtw));
-  if (mine == 2) estep_hist_mfma_run<NT, 2>(iv, lg, egp, N, KP, obs, gam32, gstat, rt0);
-  else if (mine == 1) estep_hist_mfma_run<NT, 1>(iv, lg, egp, N, KP, obs, gam32, gstat, rt0);
+  if (mine == 2) estep_hist_mfma_run<NT, 2>(iv, lg, egp, N, KP, obs, gam32, part, rt0);
+  else if (mine == 1) estep_hist_mfma_run<NT, 1>(iv, lg, egp, N, KP, obs, gam32, part, rt0);
 #if TEHMM_ESTEP_HW < 4
-  else if (mine == 3) estep_hist_mfma_run<NT, 3>(iv, lg, egp, N, KP, obs, gam32, gstat, rt0);
-  else if (mine == 4) estep_hist_mfma_run<NT, 4>(iv, lg, egp, N, KP, obs, gam32, gstat, rt0);
+  else if (mine == 3) estep_hist_mfma_run<NT, 3>(iv, lg, egp, N, KP, obs, gam32, part, rt0);
+  else if (mine == 4) estep_hist_mfma_run<NT, 4>(iv, lg, egp, N, KP, obs, gam32, part, rt0);
 #endif
 }
 
@@ -454,15 +475,17 @@ __global__ __launch_bounds__(TEHMM_ESTEP_HW * 64) void k_estep_hist_mfma(Interva
 template <int NT>
 __global__ __launch_bounds__(512) void k_estep_hist_lds(IntervalTab iv, LaneGeom lg, const EstepGroups *__restrict__ egp,
                                                         int N, int KP, const uint8_t *__restrict__ obs,
-                                                        const float *__restrict__ gam32, double *gstat) {
+                                                        const float *__restrict__ gam32, double *part, int shift) {
   using G = EstepGeom<NT>;
   constexpr int KS = G::KS, P = G::P;
   extern __shared__ double estep_lds[];
   const int grp = blockIdx.y;
   const int s0 = egp->first[grp], nslot = egp->first[grp + 1] - s0, rows = egp->rows[grp];
-  double *hist = estep_lds;
+  // fixed point: value * 2^shift as a 64-bit integer (gamma <= 1; 2^(62 - shift) bounds what one workgroup can add up)
+  unsigned long long *hist = (unsigned long long *)estep_lds;
+  const double fscale = ldexp(1.0, shift), finv = ldexp(1.0, -shift);
   int *tinfo = (int *)(hist + (size_t)rows * NT);
-  for (int i = threadIdx.x; i < rows * NT; i += blockDim.x) hist[i] = 0.0;
+  for (int i = threadIdx.x; i < rows * NT; i += blockDim.x) hist[i] = 0ull;
   for (int i = threadIdx.x; i < nslot; i += blockDim.x) tinfo[i] = egp->info[s0 + i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -504,25 +527,71 @@ __global__ __launch_bounds__(512) void k_estep_hist_lds(IntervalTab iv, LaneGeom
         // (a symbol beyond the track's last one lands in the reference's padding cells, which
         //  emission.maximize never reads: not booked)
         if (live && sym < cnt) {
-          double *hr = hist + (size_t)(lb + sym) * NT + kq;
+          unsigned long long *hr = hist + (size_t)(lb + sym) * NT + kq;
 #pragma unroll
           for (int k = 0; k < KS; ++k)
-            if (kq + 4 * k < N) atomicAdd(hr + 4 * k, (double)((k & 1) ? gc[k >> 1].y : gc[k >> 1].x));
+            if (kq + 4 * k < N)
+              atomicAdd(hr + 4 * k, (unsigned long long)__double2ll_rn((double)((k & 1) ? gc[k >> 1].y : gc[k >> 1].x) * fscale));
         }
       }
     }
   }
   __syncthreads();
-  // flush: LDS row (lbase + s) -> global row (gbase + s)
-  for (int j = 0; j < nslot; ++j) {
-    const int inf = tinfo[j];
-    const int cnt = (inf >> 7) & 511, lb = (int)((unsigned)inf >> 16);
-    const int gb = egp->gbase[s0 + j];
-    for (int i = threadIdx.x; i < cnt * NT; i += blockDim.x) {
-      const double v = hist[(size_t)lb * NT + i];
-      if (v != 0.0) estep_atomic_add(&gstat[(int64_t)gb * NT + i], v);
-    }
+  // flush: this workgroup's slot of the group's partial buffer, [gridDim.x][rows of the group][NT] behind the groups
+  // before it; k_estep_fold_lds maps LDS rows to rows of the statistics table
+  size_t goff = 0;
+  for (int g = 0; g < grp; ++g) goff += (size_t)gridDim.x * egp->rows[g] * NT;
+  double *slot = part + goff + (size_t)blockIdx.x * rows * NT;
+  for (int i = threadIdx.x; i < rows * NT; i += blockDim.x) slot[i] = (double)(long long)hist[i] * finv;
+}
+
+// ---- the ordered sums over the writers' slots (one thread per cell, slots ascending) ----------------------------
+__global__ __launch_bounds__(256) void k_estep_fold_xi(const double *__restrict__ part, int nslot, int N, int NT, double *gC,
+                                                       double *gstart) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int cells = NT * NT + NT;
+  if (idx >= cells) return;
+  double sum = 0.0;
+  for (int s = 0; s < nslot; ++s) sum += part[(size_t)s * cells + idx];
+  if (idx < NT * NT) {
+    if (idx / NT < N && idx % NT < N) gC[idx] += sum;
+  } else if (idx - NT * NT < N) {
+    gstart[idx - NT * NT] += sum;
   }
+}
+__global__ __launch_bounds__(256) void k_estep_fold_rows(const double *__restrict__ part, int nslot, int N, int NT,
+                                                         const EstepGroups *__restrict__ egp, double *gstat) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nrow = egp->n_rt * 16;
+  if (idx >= nrow * NT) return;
+  const int row = idx / NT, j = idx - row * NT;
+  if (egp->rt_info[row] < 0 || j >= N) return;
+  double sum = 0.0;
+  for (int s = 0; s < nslot; ++s) sum += part[(size_t)s * nrow * NT + idx];
+  gstat[(int64_t)egp->rt_grow[row] * NT + j] += sum;
+}
+// grid (x over the cells of the largest group, y = LDS group)
+__global__ __launch_bounds__(256) void k_estep_fold_lds(const double *__restrict__ part, int nslot, int N, int NT,
+                                                        const EstepGroups *__restrict__ egp, double *gstat) {
+  const int grp = blockIdx.y;
+  const int rows = egp->rows[grp];
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * NT) return;
+  const int lrow = idx / NT, j = idx - lrow * NT;
+  if (j >= N) return;
+  size_t goff = 0;
+  for (int g = 0; g < grp; ++g) goff += (size_t)nslot * egp->rows[g] * NT;
+  // which track of the group owns LDS row lrow
+  int grow = -1;
+  for (int sl = egp->first[grp]; sl < egp->first[grp + 1]; ++sl) {
+    const int inf = egp->info[sl];
+    const int cnt = (inf >> 7) & 511, lb = (int)((unsigned)inf >> 16);
+    if (lrow >= lb && lrow < lb + cnt) grow = egp->gbase[sl] + (lrow - lb);
+  }
+  if (grow < 0) return;
+  double sum = 0.0;
+  for (int s = 0; s < nslot; ++s) sum += part[goff + (size_t)s * rows * NT + idx];
+  gstat[(int64_t)grow * NT + j] += sum;
 }
 
 }  // namespace tehmm

@@ -391,6 +391,13 @@ void k_fused_fwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu
   es.finish(N, q, ms);
   const int E1 = ft.NB * ft.SB - 1;                  // last extended step the records hold
   es.begin(min(1, E1));
+  {
+    // (the same five stores once BEHIND the first begin(): every path into slot GF's wait now has at least five stores
+    //  younger than the table loads it waits for, so the compiler can make it vmcnt(5) -- see the stores in the loop)
+    float2 *ar = (float2 *)al32 + al32_index<NT>(lg, item, 0, kq) / 2;
+#pragma unroll
+    for (int p = 0; p < (KS + 1) / 2; ++p) ar[(int64_t)p * 64] = make_float2(0.f, 0.f);
+  }
 #ifdef TEHMM_STAMPS
   unsigned long long stq[4] = {0, 0, 0, 0}, stt = stamp_now();
 #define FST(i) do { const unsigned long long n_ = stamp_now(); stq[i] += n_ - stt; stt = n_; } while (0)
@@ -443,12 +450,20 @@ void k_fused_fwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu
     (void)ms_now;
     es.begin(min(s + 2 + Wu, E1));        // next step's gather: its first loads go out ahead of the stores below
     FST(2);
-    if (s >= 0 && run) {
-      // alpha' row as floats: five float2 per lane (states kq + 4 (2p), kq + 4 (2p + 1)), 512 bytes per wave store
-      float2 *ar = (float2 *)al32 + al32_index<NT>(lg, item, s, kq) / 2;
+    {
+      // alpha' row as floats: five float2 per lane (states kq + 4 (2p), kq + 4 (2p + 1)), 512 bytes per wave store.
+      // UNCONDITIONAL (round 4): the warm-up steps write their vectors to the row of position 0, which step 0
+      // overwrites, and lanes whose item is not run write rows that the exact chain rewrites (it walks those items
+      // whole) or nobody reads.  With the stores behind a branch the wait for the table rows requested ahead of them
+      // (slot GF of the next step) has to be vmcnt(0) -- on the path without stores nothing younger is outstanding --
+      // and then waits for the stores' acknowledgement as well: ~1 us in the middle of every step's MFMA loop.
+      float2 *ar = (float2 *)al32 + al32_index<NT>(lg, item, s < 0 ? 0 : s, kq) / 2;
 #pragma unroll
       for (int p = 0; p < (KS + 1) / 2; ++p)
-        ar[(int64_t)p * 64] = make_float2((float)v[2 * p], 2 * p + 1 < KS ? (float)v[2 * p + 1] : 0.f);
+        ar[(int64_t)p * 64] = run ? make_float2((float)v[2 * p], 2 * p + 1 < KS ? (float)v[2 * p + 1] : 0.f)
+                                  : make_float2(0.f, 0.f);           // (zeros, not this lane's meaningless vector)
+    }
+    if (s >= 0 && run) {
       if ((s & 31) == 31) {
         if (kq == 0) slog32[item * (L / 32) + (s >> 5)] = slog;
         if ((s & 63) == 31) {                              // fp64 row where the exact chain checks its direction
@@ -482,7 +497,8 @@ template <int NT, bool LOGDOM, bool EPS, bool ESTEP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= TEHMM_FUSED_2W ? 2 : 1, NT <= TEHMM_FUSED_2W ? 2 : 1)))
 void k_fused_bwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu,
                  const double *__restrict__ tab /* A, [NT][NT] row-major */, const float *__restrict__ al32,
-                 double *post, double *pre, double *end, double *chk, float *gam32 = nullptr, float *wz32 = nullptr) {
+                 double *post, double *pre, double *end, double *chk, float *gam32 = nullptr, float *wz32 = nullptr,
+                 double *sink = nullptr /* [tiles][64]: where the masked elements of the posterior stores go */) {
   using G = FusedGeom<NT>;
   constexpr int KS = G::KS, RT = G::RT;
   extern __shared__ double fused_lds[];
@@ -565,11 +581,15 @@ void k_fused_bwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu
     for (int rt = 0; rt < RT; ++rt) acc[rt] = (lane_d4){0.0, 0.0, 0.0, 0.0};
     // (the gather of position s - 1 was begun before the previous step's stores, see k_fused_fwd)
     // alpha' row of this position (official range only; floats, five float2 per lane)
+    // (loaded at EVERY step, the warm-up steps read the row of position L - 1 for nothing: a fixed number of
+    //  vector-memory operations per step lets the compiler count its waits instead of draining -- see the stores below)
     float2 alp[(KS + 1) / 2];
-    if (s < L) {
-      const float2 *ar = (const float2 *)al32 + al32_index<NT>(lg, item, s, kq) / 2;
+    {
+      const float2 *ar = (const float2 *)al32 + al32_index<NT>(lg, item, s < L ? s : L - 1, kq) / 2;
+      // (all five requested together, whatever `run` says -- every lane's row exists: left alone the compiler sinks each
+      //  load behind a test of `run` and waits for it on the spot, five dependent round trips to L2 / HBM per step)
 #pragma unroll
-      for (int p = 0; p < (KS + 1) / 2; ++p) alp[p] = run ? ar[(int64_t)p * 64] : make_float2(0.f, 0.f);
+      for (int p = 0; p < (KS + 1) / 2; ++p) alp[p] = ar[(int64_t)p * 64];
     }
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
@@ -579,6 +599,11 @@ void k_fused_bwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu
       __builtin_amdgcn_sched_barrier(0);
     }
     FST(0);
+    // (the alpha' row is USED here, unconditionally as far as the compiler can tell: its wait sits behind the MFMA loop)
+#pragma unroll
+    for (int p = 0; p < (KS + 1) / 2; ++p) asm volatile("" : "+v"(alp[p].x), "+v"(alp[p].y));
+#pragma unroll
+    for (int p = 0; p < (KS + 1) / 2; ++p) alp[p] = run ? alp[p] : make_float2(0.f, 0.f);
     double qn[KS], msn = 0.0;
     es.finish(N, qn, msn);
     FST(1);
@@ -596,9 +621,15 @@ void k_fused_bwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu
       bt[k] = acc[k >> 2][k & 3] * scale;                                  // beta_t
       if (s >= L && s == top) bt[k] = kq + 4 * k < N ? 1.0 : 0.0;           // uniform start
     }
+    double g[KS];
+    float wzf[ESTEP ? KS : 1];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) g[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < (ESTEP ? KS : 1); ++k) wzf[k] = 0.f;
     if (s < L) {
       // posterior row: normalise(alpha' * beta) in registers, straight to post [T][N]
-      double g[KS], gt = 0.0;
+      double gt = 0.0;
 #pragma unroll
       for (int k = 0; k < KS; ++k) {
         g[k] = (double)((k & 1) ? alp[k >> 1].y : alp[k >> 1].x) * bt[k];
@@ -611,7 +642,6 @@ void k_fused_bwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu
         g[k] *= inv;
         if (EPS) g[k] = (g[k] + eps) * inv_epsden;
       }
-      float wzf[ESTEP ? KS : 1];
       if constexpr (ESTEP) {
         const double wzs = scale * inv;                    // v is still w_{t+1} here
 #pragma unroll
@@ -621,48 +651,72 @@ void k_fused_bwd(IntervalTab iv, FusedTab ft, LaneGeom lg, int N, int CS, int Wu
       for (int k = 0; k < KS; ++k) v[k] = q[k] * bt[k];
 #pragma unroll
       for (int k = 0; k < KS; ++k) q[k] = qn[k];
-      es.begin(max(s - 2 + Wu, 0));       // next step's gather: its first loads go out ahead of the stores below
-      if constexpr (ESTEP) {
-        if (run) {
-          // gamma and wz rows as floats in the alpha' layout: (KS + 1) / 2 stores of 512 bytes per wave and row
-          const int64_t ai = al32_index<NT>(lg, item, s, kq) / 2;
-          float2 *gr = (float2 *)gam32 + ai, *wr = (float2 *)wz32 + ai;
+    }
+    if (s >= L) {                          // warm-up steps: no posterior
 #pragma unroll
-          for (int p = 0; p < (KS + 1) / 2; ++p) {
-            gr[(int64_t)p * 64] = make_float2((float)g[2 * p], 2 * p + 1 < KS ? (float)g[2 * p + 1] : 0.f);
-            wr[(int64_t)p * 64] = make_float2(wzf[2 * p], 2 * p + 1 < KS ? wzf[2 * p + 1] : 0.f);
-          }
+      for (int k = 0; k < KS; ++k) v[k] = s > top ? 0.0 : q[k] * bt[k];
+#pragma unroll
+      for (int k = 0; k < KS; ++k) q[k] = qn[k];
+    }
+    es.begin(max(s - 2 + Wu, 0));         // next step's gather: its first loads go out ahead of the stores below
+    // The stores of a step are UNCONDITIONAL and always the same number (round 4): masked elements -- padding columns,
+    // items that are not run, the warm-up steps -- go to a per-wave sink (ESTEP: to the row of position L - 1, which the
+    // first official step overwrites; rows of items that are not run are rewritten by the exact chain).  Behind a
+    // branch their number depends on the path, the waits for the table rows requested ahead of them become vmcnt(0),
+    // and every step's MFMA loop then waits for the previous step's stores to be acknowledged.
+    {
+      const bool off = s < L;
+      if constexpr (ESTEP) {
+        const int64_t ai = al32_index<NT>(lg, item, off ? s : L - 1, kq) / 2;
+        float2 *gr = (float2 *)gam32 + ai, *wr = (float2 *)wz32 + ai;
+#pragma unroll
+        for (int p = 0; p < (KS + 1) / 2; ++p) {
+          // (lanes whose item is not run write zeros: the reductions read slots beyond an interval's end, which the
+          //  exact chain never rewrites)
+          gr[(int64_t)p * 64] = run ? make_float2((float)g[2 * p], 2 * p + 1 < KS ? (float)g[2 * p + 1] : 0.f)
+                                    : make_float2(0.f, 0.f);
+          wr[(int64_t)p * 64] = run ? make_float2(wzf[2 * p], 2 * p + 1 < KS ? wzf[2 * p + 1] : 0.f)
+                                    : make_float2(0.f, 0.f);
         }
       } else {
 #pragma unroll
-      for (int k = 0; k < KS; ++k) *(lds_f64 *)(size_t)(ptile + (unsigned)(((lane & 15) * NT + kq + 4 * k) * 8)) = g[k];
-      int lane_v = lane;                                   // (opaque: keeps the per-store index arithmetic inside
-      asm volatile("" : "+v"(lane_v));                     //  the step instead of 27 hoisted registers)
+        for (int k = 0; k < KS; ++k) *(lds_f64 *)(size_t)(ptile + (unsigned)(((lane & 15) * NT + kq + 4 * k) * 8)) = g[k];
+        int lane_v = lane;                                   // (opaque: keeps the per-store index arithmetic inside
+        asm volatile("" : "+v"(lane_v));                     //  the step instead of 27 hoisted registers)
+        double *const snk = sink + ((int64_t)tile << 6) + lane;
+        int offv = off ? 1 : 0;                              // (opaque and per lane: as a uniform condition the compiler
+        asm volatile("" : "+v"(offv));                       //  splits the nine stores into two branchy versions)
+        // all LDS reads of the step first, then the stores (read - wait - store nine times over cost nine LDS round
+        // trips in a row: 2.7 of the 5.6 thousand cycles this tail took)
+        constexpr int NJ = (16 * NT + 63) / 64;
+        double val[NJ];
+        long long rbase[NJ];
 #pragma unroll
-      for (int j = 0; j < (16 * NT + 63) / 64; ++j) {
-        const int e = 64 * j + lane_v;                     // element of the [16][NT] tile, row-major
-        if (16 * NT % 64 == 0 || e < 16 * NT) {
-          const int r = (e * (65536 / NT + 1)) >> 16, c = e - r * NT;        // e / NT, e % NT (e < 16 NT <= 1024)
-          const double val = *(lds_f64 *)(size_t)(ptile + (unsigned)e * 8u);
-          const long long base = *(lds_i64 *)(size_t)(pinfo + (unsigned)r * 8u);
-          if (base >= 0 && c < N) post[base + (int64_t)s * N + c] = val;
+        for (int j = 0; j < NJ; ++j) {
+          const int e = 64 * j + lane_v;                     // element of the [16][NT] tile, row-major
+          const int ec = (16 * NT % 64 == 0 || e < 16 * NT) ? e : 0;
+          const int r = (ec * (65536 / NT + 1)) >> 16;       // e / NT (e < 16 NT <= 1024)
+          val[j] = *(lds_f64 *)(size_t)(ptile + (unsigned)ec * 8u);
+          rbase[j] = *(lds_i64 *)(size_t)(pinfo + (unsigned)r * 8u);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int e = 64 * j + lane_v;
+          const int ec = (16 * NT % 64 == 0 || e < 16 * NT) ? e : 0;
+          const int r = (ec * (65536 / NT + 1)) >> 16, c = ec - r * NT;
+          const bool real = (offv != 0) & (rbase[j] >= 0) & (c < N) & (16 * NT % 64 == 0 || e < 16 * NT);
+          double *dst = real ? post + (rbase[j] + (int64_t)s * N + c) : snk;
+          asm volatile("" : "+v"(dst));                      // (ONE store through the selected pointer, no branches;
+          *(__attribute__((address_space(1))) double *)dst = val[j];   //  a GLOBAL store: flat ones drain vmcnt)
         }
       }
-      }
-      if (run) {
+      if (off && run) {
         if ((s & 63) == 31) {
           double *cr = chk + (item * (L / 64) + (s >> 6)) * NT + kq;
 #pragma unroll
           for (int k = 0; k < KS; ++k) cr[4 * k] = bt[k];
         }
       }
-    }
-    if (s >= L) {                          // warm-up steps: no posterior, nothing stored
-#pragma unroll
-      for (int k = 0; k < KS; ++k) v[k] = s > top ? 0.0 : q[k] * bt[k];
-#pragma unroll
-      for (int k = 0; k < KS; ++k) q[k] = qn[k];
-      es.begin(max(s - 2 + Wu, 0));
     }
     FST(2);
     ms = msn;

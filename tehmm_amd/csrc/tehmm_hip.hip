@@ -5,6 +5,7 @@
 #include "tehmm_coop.hip.h"
 #include "tehmm_lane.hip.h"
 #include "tehmm_lane3.hip.h"
+#include "tehmm_place.hip.h"
 #include "tehmm_aux.hip.h"
 #include "tehmm_fused.hip.h"
 #include "tehmm_estep.hip.h"
@@ -283,6 +284,11 @@ struct tehmm_model {
   int ldsbase[TEHMM_MAX_TRACKS];
   int lds_rows = 0, lds_zero = 0;   // LDS-staged rows (incl. one zero row at index lds_zero)
   std::vector<double> h_lt;   // [N][N] host copy (diag etc.)
+  // quantised transition tables of ALL binades TEHMM_SPEC_MIN_E .. TEHMM_PLACE_EMAX ([0] plain, [1] with the
+  // segment-ratio header blocks), built once per parameter version (ensure_qtabs) for the device-side placement
+  DBuf<double> qall[2];
+  DBuf<int> qok[2];
+  uint64_t q_version[2] = {~(uint64_t)0, ~(uint64_t)0};
 };
 
 // workspace of the fused E-step, kept with the batch so that EM iterations reuse it
@@ -297,6 +303,7 @@ struct EstepWork {
   // fused (chunk-parallel) E-step: the track groups of k_estep_reduce
   EstepGroups h_groups;
   DBuf<EstepGroups> d_groups;
+  DBuf<double> part_xi, part_rt, part_lds;   // per-writer partial sums of the reductions (folded in order)
   uint64_t groups_model = 0;
 };
 
@@ -324,6 +331,7 @@ struct LaneWork {
   DBuf<int64_t> item_t0, ifirst;
   DBuf<double> B, BH, MS, AL, BE, pre_f, end_f, pre_b, end_b, slog32;
   DBuf<double> chk, chkf;     // fused passes: speculative beta / alpha' rows at the chains' check positions
+  DBuf<double> sink;          // fused backward pass: [tiles][64] where the masked elements of its posterior stores go
   DBuf<float> AL32;           // fused passes: alpha' rows as floats (al32_index)
   DBuf<float> GAM32, WZ32;    // fused E-step: gamma and wz rows, same layout (tehmm_estep.hip.h)
   DBuf<unsigned long long> rix;   // fused passes: observation rows as table-row index records (FusedTab::rixx)
@@ -340,6 +348,11 @@ struct LaneWork {
   DBuf<VitChunks> d_vc;       // device copies of the argument tables of k_vit_lane
   DBuf<VitItems> d_vi;
   DBuf<int> vbad, vntie, vties, wk_g, wk_e, wk_items;
+  DBuf<PlaceCounts> place;     // device-side placement (tehmm_place.hip.h)
+  DBuf<int> gclass;
+  VitChunks up_vc{};           // what d_vc / d_vi hold (uploaded again only when a pointer changed)
+  VitItems up_vi{};
+  bool up_valid = false;
   // host staging of one evaluation: sources of asynchronous copies, alive until the call has
   // synchronised its streams
   std::vector<double> hs_gain, hs_cgain, hs_qt;
@@ -732,6 +745,7 @@ int tehmm_model_create(int N, int K, int S, const double *lt, const double *pi,
   if (e == hipSuccess) e = m->A.upload(hA.data(), hA.size());
   if (e == hipSuccess) e = m->AT.upload(hAT.data(), hAT.size());
   if (e == hipSuccess) e = m->pi.upload(hpi.data(), hpi.size());
+  htab.resize(htab.size() + 64, 0.0);     // (slack: k_emis_gain_lane3's last wave reads a full slice of states past NP)
   if (e == hipSuccess) e = m->tab.upload(htab.data(), htab.size());
   if (e != hipSuccess) {
     delete m;
@@ -1194,7 +1208,7 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
     }
     h_first[b->n] = (int64_t)h_iv.size();
     for (DBuf<double> *d : {&lw.B, &lw.BH, &lw.MS, &lw.AL, &lw.BE, &lw.pre_f, &lw.end_f, &lw.pre_b, &lw.end_b,
-                            &lw.slog32, &lw.vpre, &lw.vend, &lw.vgain, &lw.vtierows, &lw.vpiecemin, &lw.chk, &lw.chkf})
+                            &lw.slog32, &lw.vpre, &lw.vend, &lw.vgain, &lw.vtierows, &lw.vpiecemin, &lw.chk, &lw.chkf, &lw.sink})
       d->release();
     for (DBuf<int> *d : {&lw.ok_f, &lw.ok_b, &lw.vbad, &lw.vntie, &lw.vties, &lw.link_f, &lw.link_b, &lw.runend_f,
                          &lw.runstart_b})
@@ -1242,6 +1256,7 @@ static int lane_prepare(tehmm_batch *b, const tehmm_model *m, int CS, int L, boo
     HIPCHK(lw.lr_f.alloc((size_t)std::max(1, lw.n_groups) * 64));
     HIPCHK(lw.dl_b.alloc((size_t)std::max(1, lw.n_groups) * 64));
   }
+  if (want_fb && fused_fb && !lw.sink.p) HIPCHK(lw.sink.alloc((size_t)std::max(1, lw.n_groups) * 4 * 64));
   if (want_fb && fused_fb && !lw.chk.p) {
     HIPCHK(lw.chk.alloc((size_t)std::max(1, lw.n_groups) * 64 * (size_t)(L / 64) * m->NP));
     HIPCHK(lw.chkf.alloc((size_t)std::max(1, lw.n_groups) * 64 * (size_t)(L / 64) * m->NP));
@@ -1342,17 +1357,34 @@ static bool ratio_lane_ok(const tehmm_model *m) {
   return true;
 }
 
-template <int NT>
-static void launch_vit_lane(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const VitChunks &vc,
-                            bool quant, bool ratio, int Wu, int n_work, int e0, hipStream_t st) {
+// The chunk / item argument tables of the quantised pass live in two small device structs.  They hold pointers only, so
+// they change when a workspace is reallocated, not from call to call: upload them when they differ from what the
+// device has (a host -> device copy queued behind running kernels waits for a wave slot like any other blit).
+static int vit_lane_upload_args(tehmm_batch *b, const VitChunks &vc, hipStream_t st) {
   LaneWork &lw = b->lw;
-  const LaneGeom lg = lane_geom(lw);
   const VitItems vi = lane_vit_items(lw);
-  if (n_work <= 0) return;
+  if (lw.up_valid && lw.d_vc.p && lw.d_vi.p && std::memcmp(&lw.up_vc, &vc, sizeof(vc)) == 0 &&
+      std::memcmp(&lw.up_vi, &vi, sizeof(vi)) == 0)
+    return TEHMM_OK;
   lw.hs_vc = vc;
   lw.hs_vi = vi;
-  (void)lw.d_vc.fill_async(&lw.hs_vc, 1, st);
-  (void)lw.d_vi.fill_async(&lw.hs_vi, 1, st);
+  HIPCHK(lw.d_vc.fill_async(&lw.hs_vc, 1, st));
+  HIPCHK(lw.d_vi.fill_async(&lw.hs_vi, 1, st));
+  std::memcpy(&lw.up_vc, &vc, sizeof(vc));
+  std::memcpy(&lw.up_vi, &vi, sizeof(vi));
+  lw.up_valid = true;
+  return TEHMM_OK;
+}
+
+// n_work_dev != nullptr: the number of work units is read on the device (tehmm_place.hip.h) and n_work is only the
+// upper bound the grid is sized for; tabs / e0: the quantised tables and the binade of the first one
+template <int NT>
+static void launch_vit_lane(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const VitChunks &vc,
+                            bool quant, bool ratio, int Wu, int n_work, const double *tabs, int e0, const int *n_work_dev,
+                            hipStream_t st) {
+  LaneWork &lw = b->lw;
+  const LaneGeom lg = lane_geom(lw);
+  if (n_work <= 0) return;
   // round 4: the outputs of a step split over the three waves of a workgroup (tehmm_lane3.hip.h); TEHMM_P2_SPLIT=0
   // keeps the one-wave kernel (which also serves the smallest models)
   if constexpr (NT >= 12) {
@@ -1364,15 +1396,15 @@ static void launch_vit_lane(tehmm_batch *b, const tehmm_model *m, const Interval
         allow_lds(k_vit_lane3<NT, NW, true>, lds);
         hipLaunchKernelGGL((k_vit_lane3<NT, NW, true>), dim3(n_work), dim3(64 * NW), lds, st, iv, lg,
                            (const VitChunks *)lw.d_vc.p, (const VitItems *)lw.d_vi.p, m->N, Wu, (const int *)lw.wk_g.p,
-                           (const int *)lw.wk_e.p, n_work, (const double *)lw.qtabs.p, e0, (const double *)lw.B.p, b->tb.p,
-                           (const double *)b->ratios.p, (const int *)lw.wk_items.p);
+                           (const int *)lw.wk_e.p, n_work, tabs, e0, (const double *)lw.B.p, b->tb.p,
+                           (const double *)b->ratios.p, (const int *)lw.wk_items.p, n_work_dev);
         return;
       }
       allow_lds(k_vit_lane3<NT, NW, false>, lds);
       hipLaunchKernelGGL((k_vit_lane3<NT, NW, false>), dim3(n_work), dim3(64 * NW), lds, st, iv, lg,
                          (const VitChunks *)lw.d_vc.p, (const VitItems *)lw.d_vi.p, m->N, Wu, (const int *)lw.wk_g.p,
-                         (const int *)lw.wk_e.p, n_work, (const double *)lw.qtabs.p, e0, (const double *)lw.B.p, b->tb.p,
-                         (const double *)nullptr, (const int *)lw.wk_items.p);
+                         (const int *)lw.wk_e.p, n_work, tabs, e0, (const double *)lw.B.p, b->tb.p,
+                         (const double *)nullptr, (const int *)lw.wk_items.p, n_work_dev);
       return;
     }
   }
@@ -1380,16 +1412,55 @@ static void launch_vit_lane(tehmm_batch *b, const tehmm_model *m, const Interval
   if constexpr (NT <= TEHMM_RATIO_LANE_MAX) if (quant && ratio) {
     hipLaunchKernelGGL((k_vit_lane<NT, true, true>), grid, dim3(256), 0, st, iv, lg, (const VitChunks *)lw.d_vc.p,
                        (const VitItems *)lw.d_vi.p, m->N, Wu,
-                       (const int *)lw.wk_g.p, (const int *)lw.wk_e.p, n_work, (const double *)lw.qtabs.p, e0,
-                       (const double *)lw.B.p, b->tb.p, (const double *)b->ratios.p, (const int *)lw.wk_items.p);
+                       (const int *)lw.wk_g.p, (const int *)lw.wk_e.p, n_work, tabs, e0,
+                       (const double *)lw.B.p, b->tb.p, (const double *)b->ratios.p, (const int *)lw.wk_items.p, n_work_dev);
     return;
   }
   if (quant) {
     hipLaunchKernelGGL((k_vit_lane<NT, true>), grid, dim3(256), 0, st, iv, lg, (const VitChunks *)lw.d_vc.p,
                        (const VitItems *)lw.d_vi.p, m->N, Wu,
-                       (const int *)lw.wk_g.p, (const int *)lw.wk_e.p, n_work, (const double *)lw.qtabs.p, e0,
-                       (const double *)lw.B.p, b->tb.p, (const double *)nullptr, (const int *)lw.wk_items.p);
+                       (const int *)lw.wk_g.p, (const int *)lw.wk_e.p, n_work, tabs, e0,
+                       (const double *)lw.B.p, b->tb.p, (const double *)nullptr, (const int *)lw.wk_items.p, n_work_dev);
   }
+}
+
+// Quantised tables of every binade a score can reach, once per parameter version (device-side placement).
+static int ensure_qtabs(tehmm_model *m, bool ratio) {
+  const int w = ratio ? 1 : 0;
+  if (m->q_version[w] == m->version && m->qall[w].p) return TEHMM_OK;
+  const size_t tsz = quantised_table_size(m, ratio);
+  std::vector<double> qt((size_t)TEHMM_PLACE_NE * tsz + 64, 0.0);      // (+ one block of padding: k_vit_lane3's prefetch)
+  std::vector<int> ok((size_t)TEHMM_PLACE_NE, 0);
+  for (int e = TEHMM_SPEC_MIN_E; e <= TEHMM_PLACE_EMAX; ++e) {
+    double *dst = qt.data() + (size_t)(e - TEHMM_SPEC_MIN_E) * tsz;
+    ok[(size_t)(e - TEHMM_SPEC_MIN_E)] = (ratio ? quantised_table_ratio(m, e, dst) : quantised_table(m, e, dst)) ? 1 : 0;
+  }
+  HIPCHK(m->qall[w].upload(qt.data(), qt.size()));
+  HIPCHK(m->qok[w].upload(ok.data(), ok.size()));
+  m->q_version[w] = m->version;
+  return TEHMM_OK;
+}
+
+// Binade placement and the work list of the quantised pass on the device, in stream order behind the gain pass
+// (tehmm_place.hip.h).  Returns the upper bound of work units the quantised pass is launched for.
+static int launch_vit_place(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, int CS, bool ratio, hipStream_t st,
+                            int *n_work_max) {
+  LaneWork &lw = b->lw;
+  SpecWork &sw = b->sw;
+  static const double rel = std::getenv("TEHMM_SPEC_MARGIN") ? std::atof(std::getenv("TEHMM_SPEC_MARGIN")) : 2e-5;
+  static const int cross = !(std::getenv("TEHMM_SPEC_CROSS") && std::atoi(std::getenv("TEHMM_SPEC_CROSS")) == 0) ? 1 : 0;
+  const LaneGeom lg = lane_geom(lw);
+  hipLaunchKernelGGL(k_vit_place_chunks, dim3(std::max(1, b->n)), dim3(64), 0, st, iv, (const int64_t *)sw.first.p,
+                     (const int64_t *)sw.t0.p, (const int64_t *)lw.ifirst.p, b->n, CS, lw.L, (const double *)lw.vgain.p,
+                     (const int *)m->qok[ratio ? 1 : 0].p, rel, cross, sw.e.p, sw.gain.p);
+  const int gb = (lw.n_groups + 255) / 256;
+  hipLaunchKernelGGL(k_vit_place_count, dim3(std::max(1, gb)), dim3(256), 0, st, lg, (const int64_t *)sw.first.p,
+                     (const int *)sw.e.p, CS, lw.place.p, lw.gclass.p);
+  hipLaunchKernelGGL(k_vit_place_scan, dim3(1), dim3(64), 0, st, lw.place.p);
+  hipLaunchKernelGGL(k_vit_place_fill, dim3(std::max(1, gb)), dim3(256), 0, st, lg, (const int64_t *)sw.first.p,
+                     (const int *)sw.e.p, CS, lw.place.p, (const int *)lw.gclass.p, lw.wk_g.p, lw.wk_e.p, lw.wk_items.p);
+  *n_work_max = 2 * lw.n_groups + TEHMM_PLACE_NE;
+  return TEHMM_OK;
 }
 
 template <int NT>
@@ -1430,6 +1501,30 @@ template <int NT>
 static void launch_emis_gain_lane(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em,
                                   int CS, int Wu, bool ratio, hipStream_t st) {
   LaneWork &lw = b->lw;
+  // round 4: the states of a row split over the three waves of a unit (tehmm_lane3.hip.h); TEHMM_EMIS_SPLIT=0 keeps
+  // the one-wave kernel (which also serves the smallest models)
+  if constexpr (NT >= 12) {
+    // (measured, 36 states: 1.1 Mb 0.98 ms against 1.70; 100 Mb 17.4 against 14.7 -- three waves repeat the observation
+    //  decode and the bookkeeping of a position, and a full GPU is short of vector issue slots, not of waves: the split
+    //  form serves the batches that leave the one-wave kernel fewer than two waves per SIMD)
+    const char *es = std::getenv("TEHMM_EMIS_SPLIT");
+    const bool split = es ? std::atoi(es) != 0 : lw.n_groups < 2048;
+    if (split) {
+      constexpr int NW = TEHMM_P2_NW, NU = 2;
+      const size_t lds3 = Emis3Geom<NT, NW, NU>::lds_bytes(em.lds_rows);
+      const dim3 grid3((lw.n_groups + NU - 1) / NU);
+      if constexpr (NT <= TEHMM_RATIO_LANE_MAX) if (ratio) {
+        allow_lds(k_emis_gain_lane3<NT, NW, NU, true>, lds3);
+        hipLaunchKernelGGL((k_emis_gain_lane3<NT, NW, NU, true>), grid3, dim3(64 * NW * NU), lds3, st, iv, em, lane_geom(lw),
+                           m->N, CS, Wu, (const float *)m->ltP.p, lw.B.p, lw.vgain.p, (const double *)b->ratios.p);
+        return;
+      }
+      allow_lds(k_emis_gain_lane3<NT, NW, NU, false>, lds3);
+      hipLaunchKernelGGL((k_emis_gain_lane3<NT, NW, NU, false>), grid3, dim3(64 * NW * NU), lds3, st, iv, em, lane_geom(lw),
+                         m->N, CS, Wu, (const float *)m->ltP.p, lw.B.p, lw.vgain.p, (const double *)nullptr);
+      return;
+    }
+  }
   const size_t lds = (size_t)em.lds_rows * NT * sizeof(double);
   if constexpr (NT <= TEHMM_RATIO_LANE_MAX) if (ratio) {
     allow_lds(k_emis_gain_lane<NT, true>, lds);
@@ -1627,7 +1722,7 @@ static int launch_fused_fb(tehmm_batch *b, const tehmm_model *m, const IntervalT
     } else {                                                                                                        \
       hipLaunchKernelGGL((k_fused_bwd<NT, LOG_, true>), gridm, dim3(256), lds_b, st, iv, ft, lg, m->N, fc.CS,         \
                          Wu, (const double *)m->A.p, (const float *)lw.AL32.p, b->post.p, lw.pre_b.p, lw.end_b.p,    \
-                         lw.chk.p);                                                                                  \
+                         lw.chk.p, (float *)nullptr, (float *)nullptr, lw.sink.p);                                   \
     }                                                                                                               \
   } while (0)
   if (m->ptab_log) TEHMM_FUSED_LAUNCH(true);
@@ -2275,11 +2370,47 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   // Where ONE chain dominates (a single 10 Mb interval: 16.0 / 18.1) mode 1 keeps the posterior passes as its partner.
   int64_t longest = 0;
   for (int i = 0; i < b->n; ++i) longest = std::max<int64_t>(longest, b->h_len[(size_t)i]);
-  const bool mid_size = b->total >= (int64_t)25000000 && b->total < (int64_t)85000000 && 4 * longest <= b->total;
-  const int defer_mode = dfs ? std::atoi(dfs) : (mid_size ? 2 : 1);
+  // Round 4 (three-wave quantised pass at 168 registers, binade placement on the device; tools/defer_sweep.py, ms per
+  // first evaluation, modes 0 / 1 / 2 / 3): 10 Mb 17.1 / 14.9 / 15.3 / 15.3, 20 Mb 22.5 / 20.1 / 20.5 / 20.4, 30 Mb
+  // 25.8 / 27.4 / 26.7 / 25.3, 50 Mb 36.3 / 40.7 / 37.5 / 37.2, 70 Mb 51.6 / 55.4 / 53.5 / 48.1, 100 Mb 65.2 / 70.5 /
+  // 67.7 / 65.1; one 10 Mb interval 16.7 / 15.9 / 17.2 / 16.8.  With the host out of the Viterbi pipeline the overlapped
+  // orders win from 25 Mb up: mode 3 there, mode 1 below and where one chain dominates.
+  const bool big = b->total >= (int64_t)25000000 && 4 * longest <= b->total;
+  const int defer_mode = dfs ? std::atoi(dfs) : (big ? 3 : 1);
   const bool defer_post = vit && postr && vspec && (defer_mode == 1 || defer_mode == 3);
   const bool split_post = defer_post && defer_mode == 3 && flane && fused_fb && vlane;
   if (postr) (void)hipEventRecord(b->ev[eP], b->sP);
+  // Binade placement on the device (tehmm_place.hip.h; TEHMM_DEVICE_PLACE=0: the host path of rounds 1..3): everything
+  // the quantised pass needs besides the gains -- zeroed flags, the argument structs, the tables of all binades -- is
+  // put on the stream BEFORE the gain pass, so that nothing but four small kernels separates the two passes.
+  static const bool dev_place_on = !(std::getenv("TEHMM_DEVICE_PLACE") && std::atoi(std::getenv("TEHMM_DEVICE_PLACE")) == 0);
+  const bool dev_place = dev_place_on && vlane && emis_gain;
+  if (vspec) {
+    vc.iv = sw.iv.p; vc.t0 = sw.t0.p; vc.first = sw.first.p; vc.n = sw.n_chunks; vc.CS = CS;
+    vc.e = sw.e.p; vc.gain = sw.gain.p; vc.ok = sw.ok.p; vc.wmin = sw.wmin.p; vc.rows = sw.rows.p;
+    vc.ntie = sw.ntie.p; vc.ties = sw.ties.p; vc.tierows = sw.tierows.p; vc.segmin = sw.segmin.p;
+    vc.offend = sw.offend.p; vc.clink = sw.clink.p; vc.clk = sw.clk.p;
+    vc.rtarget = sw.rtarget.p; vc.rsel = sw.rsel.p; vc.racc = sw.racc.p; vc.rmn = sw.rmn.p;
+  }
+  if (dev_place) {
+    hipStream_t st = b->sV;
+    rc = ensure_qtabs(m, ratio);
+    if (rc) return rc;
+    const size_t ng = (size_t)std::max(1, lw.n_groups);
+    HIPCHK(lw.wk_g.ensure(2 * ng + TEHMM_PLACE_NE));
+    HIPCHK(lw.wk_e.ensure(2 * ng + TEHMM_PLACE_NE));
+    HIPCHK(lw.wk_items.ensure((ng + TEHMM_PLACE_NE) * 64));
+    HIPCHK(lw.gclass.ensure(ng));
+    HIPCHK(lw.place.ensure(1));
+    HIPCHK(hipMemsetAsync(lw.place.p, 0, sizeof(PlaceCounts), st));
+    HIPCHK(hipMemsetAsync(lw.wk_items.p, 0xff, (ng + TEHMM_PLACE_NE) * 64 * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(sw.ok.p, 0, (size_t)std::max(1, sw.n_chunks) * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(sw.stats.p, 0, 2 * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(lw.vbad.p, 0, ng * 64 * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(lw.vntie.p, 0, ng * 64 * sizeof(int), st));
+    rc = vit_lane_upload_args(b, vc, st);
+    if (rc) return rc;
+  }
   if (vlane || glane) {
     // emission rows of every position, once, item-interleaved (log rows for Viterbi, linear for fwd/bwd)
     hipStream_t st = b->sV;
@@ -2304,19 +2435,16 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   if (vspec) {
     // chunk-parallel exact Viterbi: P0 (plain gains) -> binades -> P2 (quantised) -> fix-up chain
     hipStream_t st = b->sV;
-    vc.iv = sw.iv.p; vc.t0 = sw.t0.p; vc.first = sw.first.p; vc.n = sw.n_chunks; vc.CS = CS;
-    vc.e = sw.e.p; vc.gain = sw.gain.p; vc.ok = sw.ok.p; vc.wmin = sw.wmin.p; vc.rows = sw.rows.p;
-    vc.ntie = sw.ntie.p; vc.ties = sw.ties.p; vc.tierows = sw.tierows.p; vc.segmin = sw.segmin.p;
-    vc.offend = sw.offend.p; vc.clink = sw.clink.p; vc.clk = sw.clk.p;
-    vc.rtarget = sw.rtarget.p; vc.rsel = sw.rsel.p; vc.racc = sw.racc.p; vc.rmn = sw.rmn.p;
     if (glane) {
       if (!emis_gain) {
 #define CALL(NT_) launch_gain_lane<NT_>(b, m, iv, CS, WuV, st)
         TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
       }
-      gain.resize((size_t)std::max(1, lw.n_groups) * 64);
-      HIPCHK(hipMemcpyAsync(gain.data(), lw.vgain.p, gain.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      if (!dev_place) {
+        gain.resize((size_t)std::max(1, lw.n_groups) * 64);
+        HIPCHK(hipMemcpyAsync(gain.data(), lw.vgain.p, gain.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      }
     } else {
 #define CALL(NT_) launch_vit_spec<NT_>(b, m, iv, emg, vc, false, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
@@ -2491,7 +2619,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   };
   if (vit) {
     hipStream_t st = b->sV;
-    if (vlane) {
+    if (vlane && !dev_place) {
       HIPCHK(hipStreamSynchronize(st));
       // item gains -> chunk gains -> binades; one P2 wave per (group, binade) pair
       std::vector<double> &cgain = lw.hs_cgain;
@@ -2572,11 +2700,23 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
       HIPCHK(hipMemsetAsync(sw.stats.p, 0, 2 * sizeof(int), st));
       HIPCHK(hipMemsetAsync(lw.vbad.p, 0, (size_t)std::max(1, lw.n_groups) * 64 * sizeof(int), st));
       HIPCHK(hipMemsetAsync(lw.vntie.p, 0, (size_t)std::max(1, lw.n_groups) * 64 * sizeof(int), st));
+      rc = vit_lane_upload_args(b, vc, st);
+      if (rc) return rc;
       if (split_post) (void)hipStreamWaitEvent(st, b->evX[1], 0);     // the forward pass itself is through
-#define CALL(NT_) launch_vit_lane<NT_>(b, m, iv, vc, true, ratio, WuV, n_work, emin, st)
+#define CALL(NT_) launch_vit_lane<NT_>(b, m, iv, vc, true, ratio, WuV, n_work, (const double *)lw.qtabs.p, emin, (const int *)nullptr, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
-
+    }
+    if (vlane && dev_place) {
+      int n_work_max = 0;
+      rc = launch_vit_place(b, m, iv, CS, ratio, st, &n_work_max);
+      if (rc) return rc;
+      if (split_post) (void)hipStreamWaitEvent(st, b->evX[1], 0);     // the forward pass itself is through
+#define CALL(NT_) launch_vit_lane<NT_>(b, m, iv, vc, true, ratio, WuV, n_work_max, (const double *)m->qall[ratio ? 1 : 0].p, TEHMM_SPEC_MIN_E, (const int *)&lw.place.p->n_work, st)
+      TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+    }
+    if (vlane) {
 #define CALL(NT_) launch_vit_stitch<NT_>(b, m, iv, vc, st)
       TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
@@ -3256,8 +3396,8 @@ static bool estep_fused_wanted(const tehmm_model *m, const tehmm_batch *b, bool 
 }
 
 template <int NT>
-static void launch_estep_reduce(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, double *dev_stats,
-                                hipStream_t st) {
+static int launch_estep_reduce(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, double *dev_stats,
+                               hipStream_t st) {
   LaneWork &lw = b->lw;
   EstepWork &w = b->ew;
   const LaneGeom lg = lane_geom(lw);
@@ -3266,34 +3406,50 @@ static void launch_estep_reduce(tehmm_batch *b, const tehmm_model *m, const Inte
   double *gC = dev_stats + stats_off_C(m->NP), *gstart = dev_stats + stats_off_start(),
          *gstat = dev_stats + stats_off_stat(m->NP);
   // the three reductions are independent: the LDS-atomic histograms (LDS pipe) run next to the two matrix-core
-  // products on their own streams
+  // products on their own streams.  Every writer owns a slot of a partial buffer; the fold kernels add the slots in
+  // order (tehmm_estep.hip.h: reproducible sums).
   (void)hipEventRecord(b->evX[0], st);
   const int gxm = (int)std::max<int64_t>(1, std::min<int64_t>((n_tiles + 3) / 4, 512));
+  const int cells_xi = NT * NT + NT;
+  HIPCHK(w.part_xi.ensure((size_t)gxm * 4 * cells_xi));
+  int gx = 0, gxh = 0, max_rows = 0, tot_rows = 0;
   if (eg.n_lds > 0) {
-    int max_rows = 0;
-    for (int g = 0; g < eg.n_lds; ++g) max_rows = std::max(max_rows, eg.rows[g]);
+    for (int g = 0; g < eg.n_lds; ++g) { max_rows = std::max(max_rows, eg.rows[g]); tot_rows += eg.rows[g]; }
     const size_t lds = (size_t)max_rows * NT * sizeof(double) + (size_t)m->K * sizeof(int) + 16;
     allow_lds(k_estep_hist_lds<NT>, lds);
-    const int gx = (int)std::max<int64_t>(1, std::min<int64_t>((n_tiles + 7) / 8, 256));
+    gx = (int)std::max<int64_t>(1, std::min<int64_t>((n_tiles + 7) / 8, 256));
+    HIPCHK(w.part_lds.ensure((size_t)gx * tot_rows * NT));
+    // positions one workgroup can add into one cell: its tiles x 16 items x L
+    const int64_t per_wg = ((n_tiles + (int64_t)gx * 8 - 1) / ((int64_t)gx * 8)) * 8 * 16 * (int64_t)lw.L;
+    int shift = 62;
+    while (shift > 20 && (double)per_wg * std::ldexp(1.0, shift) >= 9.2e18) --shift;
     (void)hipStreamWaitEvent(b->sV, b->evX[0], 0);
     hipLaunchKernelGGL((k_estep_hist_lds<NT>), dim3(gx, eg.n_lds), dim3(512), lds, b->sV, iv, lg,
                        (const EstepGroups *)w.d_groups.p, m->N, b->KP, (const uint8_t *)b->obs.p,
-                       (const float *)lw.GAM32.p, gstat);
+                       (const float *)lw.GAM32.p, w.part_lds.p, shift);
+    hipLaunchKernelGGL(k_estep_fold_lds, dim3((max_rows * NT + 255) / 256, eg.n_lds), dim3(256), 0, b->sV,
+                       (const double *)w.part_lds.p, gx, m->N, NT, (const EstepGroups *)w.d_groups.p, gstat);
     (void)hipEventRecord(b->ev[11], b->sV);
   }
   if (eg.n_rt > 0) {
     constexpr int RTG = EstepGeom<NT>::RTG;
     (void)hipStreamWaitEvent(b->sB, b->evX[0], 0);
-    const int gxh = (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles, 768));     // one tile per workgroup at a time, 3 per CU
+    gxh = (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles, 768));     // one tile per workgroup at a time, 3 per CU
+    HIPCHK(w.part_rt.ensure((size_t)gxh * eg.n_rt * 16 * NT));
     hipLaunchKernelGGL((k_estep_hist_mfma<NT>), dim3(gxh, (eg.n_rt + RTG - 1) / RTG), dim3(TEHMM_ESTEP_HW * 64), 0, b->sB, iv, lg,
                        (const EstepGroups *)w.d_groups.p, m->N, b->KP, (const uint8_t *)b->obs.p,
-                       (const float *)lw.GAM32.p, gstat);
+                       (const float *)lw.GAM32.p, w.part_rt.p);
+    hipLaunchKernelGGL(k_estep_fold_rows, dim3((eg.n_rt * 16 * NT + 255) / 256), dim3(256), 0, b->sB,
+                       (const double *)w.part_rt.p, gxh, m->N, NT, (const EstepGroups *)w.d_groups.p, gstat);
     (void)hipEventRecord(b->evX[1], b->sB);
   }
   hipLaunchKernelGGL((k_estep_xi<NT>), dim3(gxm), dim3(256), 0, st, iv, lg, m->N, (const float *)lw.AL32.p,
-                     (const float *)lw.GAM32.p, (const float *)lw.WZ32.p, gC, gstart);
+                     (const float *)lw.GAM32.p, (const float *)lw.WZ32.p, w.part_xi.p);
+  hipLaunchKernelGGL(k_estep_fold_xi, dim3((cells_xi + 255) / 256), dim3(256), 0, st, (const double *)w.part_xi.p, gxm * 4,
+                     m->N, NT, gC, gstart);
   if (eg.n_lds > 0) (void)hipStreamWaitEvent(st, b->ev[11], 0);
   if (eg.n_rt > 0) (void)hipStreamWaitEvent(st, b->evX[1], 0);
+  return TEHMM_OK;
 }
 
 // returns TEHMM_OK and *done = true when the fused path ran; *done = false: the caller falls back
@@ -3359,9 +3515,11 @@ static int estep_fused(tehmm_model_t *m, tehmm_batch_t *b, double *dev_stats, do
 #undef CALL
   if (rcf) return rcf;
   (void)hipEventRecord(b->ev[7], st);
-#define CALL(NT_) launch_estep_reduce<NT_>(b, m, iv, dev_stats, st)
+  int rcr = TEHMM_OK;
+#define CALL(NT_) rcr = launch_estep_reduce<NT_>(b, m, iv, dev_stats, st)
   TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
+  if (rcr) return rcr;
   (void)hipEventRecord(b->ev[9], st);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st));

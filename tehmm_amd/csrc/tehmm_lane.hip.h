@@ -652,10 +652,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TEHMM_P2_WA
 void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItems *vip, int N, int Wu, const int *wk_g,
                 const int *wk_e, int n_work, const double *__restrict__ tabs, int e0,
                 const double *__restrict__ B, uint8_t *tb, const double *__restrict__ ratios = nullptr,
-                const int *__restrict__ wk_items = nullptr) {
+                const int *__restrict__ wk_items = nullptr, const int *__restrict__ n_work_dev = nullptr) {
   const int lane = threadIdx.x & 63;
   const int wk = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wave-uniform
-  if (wk >= n_work) return;
+  if (wk >= (n_work_dev ? *n_work_dev : n_work)) return;      // (device-side placement: the grid is an upper bound)
   // work unit: a whole group of 64 consecutive items (wk_g >= 0: all its chunks of binade e run), or -- groups
   // that mix binades (interval heads, binade crossings) -- a list of up to 64 items of ONE binade collected
   // over all such groups (wk_g = -(1 + slot), items wk_items[64 slot ..], -1 = empty lane)
@@ -1242,7 +1242,10 @@ __global__ __launch_bounds__(256) void k_vit_gain_lane(IntervalTab iv, LaneGeom 
 // state can emit) and gain[item] as k_vit_gain_lane.
 // ------------------------------------------------------------------------------------------
 template <int NT, bool RATIO = false>
-__global__ __launch_bounds__(256) void k_emis_gain_lane(IntervalTab iv, EmisTab em, LaneGeom lg, int N, int CS, int Wu,
+#ifndef TEHMM_EMIS_WAVES
+#define TEHMM_EMIS_WAVES 2
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TEHMM_EMIS_WAVES, TEHMM_EMIS_WAVES))) void k_emis_gain_lane(IntervalTab iv, EmisTab em, LaneGeom lg, int N, int CS, int Wu,
                                                         const float *__restrict__ tabf, double *B, double *gain,
                                                         const double *__restrict__ ratios = nullptr) {
   extern __shared__ double emis_ltab[];

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(lane3_w
 void k_vit_lane3(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItems *vip, int N, int Wu, const int *wk_g,
                  const int *wk_e, int n_work, const double *__restrict__ tabs, int e0,
                  const double *__restrict__ B, uint8_t *tb, const double *__restrict__ ratios,
-                 const int *__restrict__ wk_items) {
+                 const int *__restrict__ wk_items, const int *__restrict__ n_work_dev = nullptr) {
   using GEO = Lane3Geom<NT, NW>;
   constexpr int G = GEO::G, GW = GEO::GW;
   constexpr bool EVEN = G % NW == 0;
@@ -78,7 +78,7 @@ void k_vit_lane3(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitIte
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wk = blockIdx.x;
-  if (wk >= n_work) return;
+  if (wk >= (n_work_dev ? *n_work_dev : n_work)) return;      // (device-side placement: the grid is an upper bound)
   const int gq = wk_g[wk];
   const int e = wk_e[wk];
   // (the chunk / item tables are reached through pointers re-read in the rare paths, field by field, as GLOBAL loads)
@@ -408,6 +408,197 @@ void k_vit_lane3(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitIte
       if (anybad) LANE3_GI(lane3_gload(&vi->bad))[item] = 1;                      // (zeroed before the launch; any wave may raise it)
     }
   }
+}
+
+}  // namespace tehmm
+
+namespace tehmm {
+
+// ==========================================================================================
+// Emission rows + P0 (k_emis_gain_lane) with the STATES of a position split over the NW waves of a unit (round 4).
+//
+// k_emis_gain_lane keeps a whole fp64 emission row (72 registers), the packed-float vector and its successor per
+// lane: 236 registers, two waves per SIMD, and a dependent gather (observation word -> table row -> 18 16-byte
+// reads per track) whose latency those two waves cannot cover: the vector pipe is active 36 % of the time.  Here a
+// unit = 64 items x NW waves; wave w gathers and sums only ITS states of the row (a third of every table row), runs
+// the packed-float max-plus step for ITS outputs, and the new float vector (plus the waves' row maxima, which
+// decide whether anything can emit the row at all) goes round through LDS, one workgroup barrier per position.
+// ~130 registers -> three waves per SIMD with a third of the gather each.  Two units share one workgroup and one
+// LDS copy of the small tracks' table rows.  Outputs as k_emis_gain_lane: B (fp64 log rows, item-interleaved,
+// NaN rows where no state can emit) and gain[item].
+// ==========================================================================================
+template <int NT, int NW, int NU>
+struct Emis3Geom {
+  using L3 = Lane3Geom<NT, NW>;
+  static constexpr size_t UNIT_BYTES = (size_t)2 * (NT / 2) * 64 * sizeof(float) * 2 + (size_t)2 * NW * 64 * sizeof(double);
+  static size_t lds_bytes(int lds_rows) { return (size_t)lds_rows * NT * sizeof(double) + NU * UNIT_BYTES; }
+};
+
+// the states [j0, j0 + NS) of the emission log-likelihood row of one position (operation order per state as in
+// _emission.pyx:65-72; emis_rows of tehmm_coop.hip.h restricted to a slice; j0 even)
+template <int NT, int NS>
+__device__ __forceinline__ void emis_rows_slice(const EmisTab &e, const double *ltab, int64_t gpos, int j0, double (&x)[NS]) {
+  const uint32_t *row = e.obs32 + gpos * e.KPW;
+#pragma unroll
+  for (int j = 0; j < NS; ++j) x[j] = 0.0;
+  uint32_t wn = row[0];
+  for (int d = 0; d < e.KPW; ++d) {
+    const uint32_t w = wn;
+    if (d + 1 < e.KPW) wn = row[d + 1];
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+      const int k = 4 * d + bb;
+      if (k < e.K) {
+        const int sym = (int)((w >> (8 * bb)) & 0xffu);
+        const bool inr = sym < e.rowcnt[k];
+        const int lb = e.ldsbase[k];
+        if (lb >= 0) {
+          lds_cd2 *tr = (lds_cd2 *)(size_t)((unsigned)(size_t)(__attribute__((address_space(3))) const double *)ltab +
+                                            (unsigned)(((inr ? lb + sym : e.lds_zero) * NT + j0) * 8));
+#pragma unroll
+          for (int jj = 0; jj < NS / 2; ++jj) {
+            const d2v v = tr[jj];
+            x[2 * jj] += v.x;
+            x[2 * jj + 1] += v.y;
+          }
+        } else {
+          const double2 *tr = (const double2 *)(e.tab + (int64_t)(inr ? e.rowbase[k] + sym : e.zero_row) * NT + j0);
+#pragma unroll
+          for (int jj = 0; jj < NS / 2; ++jj) {
+            const double2 v = tr[jj];
+            x[2 * jj] += v.x;
+            x[2 * jj + 1] += v.y;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NS; ++j) x[j] *= e.normalize;
+  if (e.ratios) {
+    const double r = e.ratios[gpos];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) x[j] *= r;
+  }
+}
+
+template <int NT, int NW, int NU, bool RATIO>
+__global__ __launch_bounds__(64 * NW * NU)
+void k_emis_gain_lane3(IntervalTab iv, EmisTab em, LaneGeom lg, int N, int CS, int Wu, const float *__restrict__ tabf,
+                       double *B, double *gain, const double *__restrict__ ratios) {
+  using GEO = Lane3Geom<NT, NW>;
+  using EG = Emis3Geom<NT, NW, NU>;
+  constexpr int G = GEO::G, GW = GEO::GW, OW = 4 * GW, PW = 2 * GW;
+  constexpr bool EVEN = G % NW == 0;
+  extern __shared__ double e3_lds[];
+  double *ltab = e3_lds;
+  stage_emis_table(em, ltab, NT);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int u = wave / NW, w = wave - u * NW;
+  char *ubase = (char *)(ltab + em.lds_rows * NT) + (size_t)u * EG::UNIT_BYTES;
+  lane_f2 *Wx = (lane_f2 *)ubase;                                        // [2][NT / 2][64]
+  double *rmx = (double *)(ubase + (size_t)2 * (NT / 2) * 64 * sizeof(lane_f2));   // [2][NW][64]
+  const int g = blockIdx.x * NU + u;
+  const bool glive = g < lg.n_groups;                                   // (uniform per unit; every wave keeps the barriers)
+  const int L = lg.L;
+  const int64_t item = (int64_t)(glive ? g : 0) * 64 + lane;
+  const bool valid = glive && item < lg.n_items;
+  const int id = valid ? lg.item_iv[item] : 0;
+  const int64_t t0 = valid ? lg.item_t0[item] : 0;
+  const int64_t T = iv.len[id], p0 = iv.pos0[id];
+  const int len = valid ? (int)min((int64_t)L, T - t0) : 0;
+  const int64_t ct0 = (t0 / CS) * CS;
+  const bool run = valid && ct0 > 0 && ct0 + CS <= T;                   // P0 runs on full chunks but an interval's first
+  const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+  const int og0 = w * GW;                                               // this wave's output groups / states 4 og0 ..
+  const int ng = min(GW, G - og0);
+  lane_f2 W[NT / 2];
+#pragma unroll
+  for (int j = 0; j < NT / 2; ++j)
+    W[j] = (lane_f2){2 * j < N ? 0.f : -INFINITY, 2 * j + 1 < N ? 0.f : -INFINITY};
+  bool bad = false;
+  auto vec_max = [&]() {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NT / 2; ++j) mx = fmaxf(mx, fmaxf(W[j].x, W[j].y));
+    return mx;
+  };
+  float g0 = 0.f;
+  double xp[OW];                                                        // this wave's states of the previous position
+#pragma unroll
+  for (int j = 0; j < OW; ++j) xp[j] = 0.0;
+  bool act_prev = false;
+  // finish position sp (step counter k = its successor's): the new vector and the waves' row maxima from LDS; the row
+  // goes to B now that it is known whether ANY state can emit it
+  auto finish = [&](int sp, int k) {
+    __syncthreads();
+    const lane_f2 *src = Wx + (size_t)(k & 1) * (NT / 2) * 64 + lane;
+#pragma unroll
+    for (int jp = 0; jp < NT / 2; ++jp) W[jp] = src[jp * 64];
+    const double *rm = rmx + (size_t)((k - 1) & 1) * NW * 64 + lane;
+    double m = rm[0];
+#pragma unroll
+    for (int q = 1; q < NW; ++q) m = fmax(m, rm[q * 64]);
+    const bool good = m > -1e20;
+    if (B && sp >= 0 && act_prev) {
+      lane3_gf64 *dst = (lane3_gf64 *)B + ((((int64_t)g * L + sp) * NT + 4 * og0) << 6) + lane;
+#pragma unroll
+      for (int j = 0; j < OW; ++j)
+        if (EVEN || j < 4 * ng) dst[(int64_t)j << 6] = good ? xp[j] : qnan;
+    }
+    bad = bad | (act_prev && !good);
+  };
+  int k = 0;
+  for (int s = -Wu; s < L; ++s, ++k) {
+    if (k > 0) finish(s - 1, k);
+    if (s == 0) g0 = vec_max();
+    const bool act = s >= 0 ? s < len : run;
+    const int64_t gpos = p0 + t0 + (act ? s : 0);
+    double x[OW];
+    emis_rows_slice<NT, OW>(em, ltab, gpos, 4 * og0, x);
+    // (the last wave of an uneven split reads past the row's NT states -- the next row, the table's slack or the LDS
+    //  behind the staged rows: readable, and what lies outside its own states is not used)
+    double pm = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < OW; ++j) pm = fmax(pm, (4 * og0 + j < N && (EVEN || j < 4 * ng)) ? x[j] : -INFINITY);
+    // ---- P0 step of this wave's outputs on the row rounded to float (see k_vit_gain_lane)
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    const_f2 *tp = (const_f2 *)(size_t)tabf + z;
+    float rf = 1.f, rm1 = 0.f;
+    if (RATIO) {
+      rf = (float)ratios[gpos];
+      rm1 = rf > 1.f ? rf - 1.f : 0.f;
+    }
+    lane_f2 *dstw = Wx + ((size_t)((k + 1) & 1) * (NT / 2) + 2 * og0) * 64 + lane;
+#pragma unroll
+    for (int op = 0; op < PW; ++op) {
+      if (!EVEN && op >= 2 * ng) continue;
+      const int opg = 2 * og0 + op;                                     // (wave-uniform)
+      lane_f2 acc = (lane_f2){W[0].x, W[0].x} + tp[opg * NT];
+      if (RATIO) {
+        const lane_f2 ltd = tp[NT * NT / 2 + opg];
+        acc = acc + ltd * (lane_f2){rf - rm1, rf - rm1};
+        if (op == 0 && og0 == 0) acc.x -= ((const float *)(size_t)tabf)[z + NT * NT + NT];
+      }
+#pragma unroll
+      for (int f = 1; f < NT; ++f) {
+        const float wf = (f & 1) ? W[f >> 1].y : W[f >> 1].x;
+        acc = __builtin_elementwise_max(acc, (lane_f2){wf, wf} + tp[opg * NT + f]);
+      }
+      lane_f2 wn = acc + (lane_f2){(float)x[2 * op], (float)x[2 * op + 1]};
+      if (RATIO) wn = wn + tp[NT * NT / 2 + opg] * (lane_f2){rm1, rm1};
+      dstw[op * 64] = wn;
+    }
+    rmx[(size_t)(k & 1) * NW * 64 + w * 64 + lane] = pm;
+#pragma unroll
+    for (int j = 0; j < OW; ++j) xp[j] = x[j];
+    act_prev = act;
+  }
+  finish(L - 1, k);
+  if (run && w == 0) ((lane3_gf64 *)gain)[item] = (bad || len < L) ? qnan : (double)vec_max() - (double)g0;
 }
 
 }  // namespace tehmm

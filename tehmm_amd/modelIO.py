@@ -9,6 +9,28 @@ import json
 import numpy as np
 
 FORMAT = "tehmm_amd.model.v2"
+FORMAT_V1 = "tehmm_amd.model.v1"       # round-2 files: arrays only (no track list, value maps, flags)
+
+
+def _load_v1(z):
+    """Files written by the round-2 format: the arrays with default metadata (a multinomial emission model, no track
+    list -- evaluation data must already be encoded with the training symbols)."""
+    from .emission import IndependentMultinomialEmissionModel
+    from .hmm import MultitrackHmm
+    lp = z["log_probs"]
+    eff = float(z["eff_seg_len"])
+    em = IndependentMultinomialEmissionModel(lp.shape[1], [int(x) for x in z["symbols"]], fudge=float(z["fudge"]),
+                                             effectiveSegmentLength=None if eff < 0 else eff)
+    em.logProbs = lp.copy()
+    em.normalizeFac = float(z["normalize_fac"])
+    if z["gauss_params"].size:
+        em.gaussParams = z["gauss_params"].copy()
+    hmm = MultitrackHmm(em)
+    hmm._log_transmat = z["log_transmat"].copy()
+    hmm._log_startprob = z["log_startprob"].copy()
+    it = int(z["iteration"])
+    hmm.current_iteration = None if it < 0 else it
+    return hmm
 
 
 def _map_to_json(vm):
@@ -86,6 +108,8 @@ def loadModel(path):
     from .hmm import MultitrackHmm
     from .track import Track, TrackList
     with np.load(path, allow_pickle=False) as z:
+        if str(z["format"]) == FORMAT_V1:
+            return _load_v1(z)
         if str(z["format"]) != FORMAT:
             raise ValueError("loadModel: %s is not a %s file" % (path, FORMAT))
         meta = json.loads(str(z["meta"]))

@@ -12,7 +12,7 @@ if "--build" in sys.argv:
                            "-std=c++17", "-DTEHMM_STAMPS", "-DTEHMM_DEV_NT=36"] + [a for a in sys.argv if a.startswith("-D")] + ["-o", DIAG,
                            os.path.join(ROOT, "tehmm_amd", "csrc", "tehmm_hip.hip")])
     sys.exit(0)
-os.environ["TEHMM_HIP_LIB"] = DIAG
+os.environ.setdefault("TEHMM_HIP_LIB", DIAG)
 import torch, bench
 from tehmm_amd import _lib, synth
 from tehmm_amd.engine import HipBatch, HipModel
