@@ -1,0 +1,184 @@
+"""Round-4 GPU tests (through the C ABI): the three-wave quantised Viterbi pass and emission + P0 kernels against the
+oracle and against the one-wave kernels (even and uneven splits of the output groups, segment ratios), binade placement
+on the device against the host placement, bit-reproducible E-step statistics, the count-static fused passes on ragged
+intervals."""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_array_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def hip():
+    from tehmm_amd import _lib, build
+    build.build()
+    if _lib.device_count() < 1:
+        pytest.fail("no GPU visible: the HIP path has no CPU fallback")
+
+
+KNOBS = ("TEHMM_P2_SPLIT", "TEHMM_EMIS_SPLIT", "TEHMM_DEVICE_PLACE", "TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_DEFER",
+         "TEHMM_LANE_VIT", "TEHMM_ESTEP_FUSED")
+
+
+def _noisy_obs(model, total, seed):
+    from tehmm_amd import synth
+    piece = synth.sample_obs(model, 40_000, seed=seed)
+    obs = np.tile(piece, (total // 40_000 + 1, 1))[:total].copy()
+    rs = np.random.RandomState(seed + 1)
+    noise = rs.rand(total) < 0.3
+    for k, sk in enumerate(model.symbols_per_track):
+        obs[noise, k] = rs.randint(1, sk + 1, size=int(noise.sum()))
+    return obs
+
+
+def _eval(model, obs, offs, ratios=None, **kw):
+    from tehmm_amd.engine import HipBatch, HipModel
+    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, symbols_per_track=model.symbols_per_track)
+    hb = HipBatch(obs, offs, ratios)
+    res = hm.eval(hb, use_ratios=ratios is not None, **kw)
+    out = (hb.paths() if kw.get("viterbi") else None, res.get("viterbi_logprob"),
+           hb.posteriors() if kw.get("posterior") else None, res.get("forward_logprob"), hb.timing())
+    hb.close()
+    hm.close()
+    return out
+
+
+# N -> padded states / output groups: 9 -> 12 / 3 (one group per wave), 13 -> 16 / 4 (2, 2, 0: a wave without outputs),
+# 35 -> 36 / 9 (even), 38 -> 40 / 10 (4, 4, 2), 50 -> 56 / 14 (5, 5, 4), 60 -> 64 / 16 (6, 6, 4)
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("N,ratio", [(9, False), (13, False), (35, False), (35, True), (38, False), (50, True), (60, False)])
+def test_three_wave_passes_bit_exact(monkeypatch, N, ratio):
+    """k_vit_lane3 (quantised pass split over three waves) and k_emis_gain_lane3 against the oracle, bit for bit, and
+    against the one-wave kernels: same paths, same scores, the same number of exact blocks left to the chain."""
+    from oracle import oracle
+    from tehmm_amd import synth
+    for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    model = synth.make_model(N, (3, 5, 4, 30, 250) if N != 9 else (3, 5, 4), (4,) if N != 9 else (), seed=40 + N)
+    lens = [180_000, 70_001, 3_000, 1]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = _noisy_obs(model, int(offs[-1]), seed=N)
+    ratios = None
+    if ratio:
+        rs = np.random.RandomState(N)
+        ratios = np.minimum(1 + rs.geometric(1 / 20.0, size=int(offs[-1])), 100) / 20.0
+    got = {}
+    for tag, p2, em in (("split", "1", "1"), ("one", "0", "0")):
+        monkeypatch.setenv("TEHMM_P2_SPLIT", p2)
+        monkeypatch.setenv("TEHMM_EMIS_SPLIT", em)
+        got[tag] = _eval(model, obs, offs, ratios, viterbi=True, posterior=False)
+    for i in range(len(lens)):
+        sl = slice(int(offs[i]), int(offs[i + 1]))
+        vlp, path = oracle.decode(obs[sl], model.log_probs, model.log_startprob, model.log_transmat, 1.0,
+                                  None if ratios is None else ratios[sl])
+        for tag in ("split", "one"):
+            assert_array_equal(got[tag][0][sl], path)
+            assert got[tag][1][i] == vlp
+    ts, to = got["split"][4], got["one"][4]
+    assert ts["count:viterbi_chunk_jumps"] > 0
+    assert ts["count:viterbi_exact_blocks"] == to["count:viterbi_exact_blocks"]
+    assert ts["count:viterbi_chunk_jumps"] == to["count:viterbi_chunk_jumps"]
+
+
+@pytest.mark.timeout(900)
+def test_device_placement_matches_host_placement(monkeypatch):
+    """Binade placement and the work list of the quantised pass built on the device (tehmm_place.hip.h) against the
+    host path of rounds 1..3: same paths and scores as the oracle, the same chunks speculated and jumped."""
+    from oracle import oracle
+    from tehmm_amd import synth
+    for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    model = synth.make_model(35, seed=0)
+    lens = [400_000, 150_000, 64 * 1024 + 5, 2_000, 1]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = _noisy_obs(model, int(offs[-1]), seed=77)
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TEHMM_DEVICE_PLACE", mode)
+        got[mode] = _eval(model, obs, offs, viterbi=True, posterior=True)
+    for i in range(len(lens)):
+        sl = slice(int(offs[i]), int(offs[i + 1]))
+        vlp, path = oracle.decode(obs[sl], model.log_probs, model.log_startprob, model.log_transmat)
+        for mode in ("1", "0"):
+            assert_array_equal(got[mode][0][sl], path)
+            assert got[mode][1][i] == vlp
+    assert got["1"][4]["count:viterbi_exact_blocks"] == got["0"][4]["count:viterbi_exact_blocks"]
+    assert got["1"][4]["count:viterbi_chunk_jumps"] == got["0"][4]["count:viterbi_chunk_jumps"] > 0
+    assert_array_equal(got["1"][2], got["0"][2])          # (the posterior pipeline does not depend on the placement)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("N,symbols,gauss", [(35, None, None), (50, (4, 250, 30, 250, 250), (1, 3, 4))])
+def test_estep_statistics_bit_reproducible(monkeypatch, N, symbols, gauss):
+    """Same input -> same bits (round 4): the fused E-step three times on fresh batch handles and twice per handle gives
+    IDENTICAL statistics and log-likelihood -- the reductions fold per-writer partial sums in a fixed order and the LDS
+    histograms are fixed-point integers -- and they agree with the oracle at 1e-6."""
+    from oracle import oracle
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    model = (synth.make_model(N, synth.CONFIG4_SYMBOLS, synth.CONFIG4_GAUSSIAN, seed=12) if symbols is None
+             else synth.make_model(N, symbols, gauss, seed=12 + N))
+    lens = [100_000] * 6 + [33_333, 1, 2_500]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = synth.sample_obs(model, int(offs[-1]), seed=5, missing=0.02)
+    K, _, S = model.log_probs.shape
+    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, 1.0, model.symbols_per_track)
+    runs = []
+    for _rep in range(3):
+        hb = HipBatch(obs, offs)
+        for _again in range(2):
+            start, trans, st = np.zeros(N), np.zeros((N, N)), np.zeros((K, N, S))
+            lp = hm.estep(hb, False, start, trans, st)
+            runs.append((lp, start, trans, st))
+        assert "estep_reduce" in hb.timing()               # (the chunk-parallel path ran)
+        hb.close()
+    hm.close()
+    for r in runs[1:]:
+        assert r[0] == runs[0][0]
+        assert_array_equal(r[1], runs[0][1])
+        assert_array_equal(r[2], runs[0][2])
+        assert_array_equal(r[3], runs[0][3])
+    ref = oracle.estep([obs[offs[i]:offs[i + 1]] for i in range(len(lens))], model.log_probs, model.log_startprob,
+                       model.log_transmat, 1.0, None)
+    assert_allclose(runs[0][0], ref["logprob"], rtol=1e-9)
+    assert_allclose(runs[0][2], ref["trans"], rtol=1e-6, atol=1e-9)
+    assert_allclose(runs[0][3], ref["obs"], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.timeout(900)
+def test_fused_passes_ragged_geometry_vs_oracle(monkeypatch):
+    """The fused forward / backward passes store unconditionally since round 4 (warm-up steps and lanes whose item is
+    not run write rows that are overwritten or never read): ragged intervals -- tails shorter than a chunk, one-row and
+    sub-chunk intervals, a last group with empty lanes -- with small chunks so that every kind of item occurs; posteriors
+    and log-likelihoods against the oracle at 1e-6, and a second evaluation of the same batch gives the same bits."""
+    from oracle import oracle
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("TEHMM_SPEC_CHUNK", "256")
+    monkeypatch.setenv("TEHMM_LANE_SUB", "128")
+    model = synth.make_model(35, seed=3)
+    lens = [9_000, 1, 255, 256, 257, 4_097, 700, 12_345]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = synth.sample_obs(model, int(offs[-1]), seed=9, missing=0.05)
+    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, symbols_per_track=model.symbols_per_track)
+    hb = HipBatch(obs, offs)
+    res = hm.eval(hb, viterbi=True, posterior=True)
+    post = hb.posteriors().copy()
+    paths = hb.paths().copy()
+    res2 = hm.eval(hb, viterbi=True, posterior=True)
+    assert_array_equal(hb.posteriors(), post)
+    assert_array_equal(hb.paths(), paths)
+    assert_array_equal(res2["forward_logprob"], res["forward_logprob"])
+    hb.close()
+    hm.close()
+    ref_paths, ref_vlp, ref_flp, ref_post = oracle.eval_batch(obs, offs, model.log_probs, model.log_startprob,
+                                                               model.log_transmat)
+    assert_array_equal(paths, ref_paths)
+    assert_array_equal(res["viterbi_logprob"], ref_vlp)
+    assert_allclose(res["forward_logprob"], ref_flp, rtol=1e-9)
+    assert_allclose(post, ref_post, rtol=1e-6, atol=1e-12)
