@@ -432,6 +432,19 @@ def extras(args, model, hm, hb, obs, offs, lens, device, torch, mk_model):
                                                      "evaluation, D2H into pinned host memory from the library's pool"
                                                      + (" (first call: the pool is empty, pinning included)"
                                                         if tag.endswith("first_call") else "; best of three"))
+        # the same job with the transfer hidden behind the evaluation (engine.eval_stream: interval groups, a worker
+        # thread evaluates group g + 1 while group g's results cross PCIe)
+        from tehmm_amd.engine import eval_stream
+        times = []
+        for _rep in range(3):
+            t1 = time.perf_counter()
+            ps, qs, _, _ = eval_stream(hm, host_obs, o2, group_rows=4_000_000)
+            times.append(time.perf_counter() - t1)
+            del ps, qs
+        ex["end_to_end_pcie_full_posteriors_streamed"] = rate(
+            n2, min(times), positions=n2, ms_all=[round(t * 1e3, 1) for t in times],
+            note="as end_to_end_pcie_full_posteriors, in groups of ~4 Mb: H2D + evaluation of group g + 1 on a worker "
+                 "thread while group g's paths and posterior rows are fetched; best of three")
         del host_obs
     hb.close()
     torch.cuda.empty_cache()

@@ -316,6 +316,7 @@ struct SpecWork {
   DBuf<int64_t> t0, first;
   DBuf<double> gain, wmin, rows, tierows, scale, wstart, segmin, offend, clk, racc, rmn;
   DBuf<int64_t> rtarget, rsel;
+  DBuf<unsigned> tsoft, tpar;
   DBuf<int> clink;
 };
 
@@ -353,6 +354,7 @@ struct LaneWork {
   VitChunks up_vc{};           // what d_vc / d_vi hold (uploaded again only when a pointer changed)
   VitItems up_vi{};
   bool up_valid = false;
+  int soft_ties = 0;           // the last quantised pass went through rounding ties keeping its frame (tehmm_lane3.hip.h)
   // host staging of one evaluation: sources of asynchronous copies, alive until the call has
   // synchronised its streams
   std::vector<double> hs_gain, hs_cgain, hs_qt;
@@ -1050,7 +1052,11 @@ static void launch_fb_coop(tehmm_batch *b, const tehmm_model *m, const IntervalT
 // ---- speculative chunk-parallel exact Viterbi (no segment ratios) ----------------------------
 static int spec_chunk_size() {
   const char *s = std::getenv("TEHMM_SPEC_CHUNK");     // 0 disables; tests use small chunks
-  int cs = s ? std::atoi(s) : 1024;
+  // (round 4: 512 instead of 1024 -- a chunk that crosses into the next binade is walked exactly up to the crossing,
+  //  half a chunk on average, and with the rounding ties passed those walks were what the chain still did: one 10 Mb
+  //  interval 15.6 -> 13.7 ms, exact blocks 452 -> 359; 256: 14.9 ms, the per-chunk kernels then cost more than
+  //  the chain saves)
+  int cs = s ? std::atoi(s) : 512;
   if (cs <= 0) return 0;
   return std::max(64, (cs + 63) & ~63);
 }
@@ -1091,10 +1097,14 @@ static int spec_prepare(tehmm_batch *b, const tehmm_model *m, int CS) {
   HIPCHK(sw.segmin.alloc(nc * (TEHMM_SPEC_MAXT + 1)));
   HIPCHK(sw.offend.alloc(nc));
   HIPCHK(sw.clk.alloc(nc));
-  HIPCHK(sw.racc.alloc(nc));
-  HIPCHK(sw.rmn.alloc(nc));
-  HIPCHK(sw.rtarget.alloc(nc));
-  HIPCHK(sw.rsel.alloc(nc));
+  HIPCHK(sw.racc.alloc(2 * nc));           // (the run scan is kept per parity of the chain's delta: [2][chunks])
+  HIPCHK(sw.rmn.alloc(2 * nc));
+  HIPCHK(sw.rtarget.alloc(2 * nc));
+  HIPCHK(sw.rsel.alloc(2 * nc));
+  HIPCHK(sw.tsoft.alloc(nc));
+  HIPCHK(sw.tpar.alloc(nc));
+  HIPCHK(hipMemset(sw.tsoft.p, 0, nc * sizeof(unsigned)));
+  HIPCHK(hipMemset(sw.tpar.p, 0, nc * sizeof(unsigned)));
   HIPCHK(sw.clink.alloc(nc));
   HIPCHK(hipMemset(sw.clink.p, 0, nc * sizeof(int)));
   return TEHMM_OK;
@@ -1384,11 +1394,12 @@ static void launch_vit_lane(tehmm_batch *b, const tehmm_model *m, const Interval
                             hipStream_t st) {
   LaneWork &lw = b->lw;
   const LaneGeom lg = lane_geom(lw);
+  lw.soft_ties = 0;
   if (n_work <= 0) return;
   // round 4: the outputs of a step split over the three waves of a workgroup (tehmm_lane3.hip.h); TEHMM_P2_SPLIT=0
   // keeps the one-wave kernel (which also serves the smallest models)
   if constexpr (NT >= 12) {
-    static const bool split = !(std::getenv("TEHMM_P2_SPLIT") && std::atoi(std::getenv("TEHMM_P2_SPLIT")) == 0);
+    const bool split = !(std::getenv("TEHMM_P2_SPLIT") && std::atoi(std::getenv("TEHMM_P2_SPLIT")) == 0);
     if (quant && split) {
       constexpr int NW = TEHMM_P2_NW;
       const size_t lds = Lane3Geom<NT, NW>::LDS_BYTES;
@@ -1400,11 +1411,14 @@ static void launch_vit_lane(tehmm_batch *b, const tehmm_model *m, const Interval
                            (const double *)b->ratios.p, (const int *)lw.wk_items.p, n_work_dev);
         return;
       }
+      // soft ties (TEHMM_SOFT_TIES=0: every rounding tie ends a piece, as in rounds 2 and 3)
+      const bool soft = !(std::getenv("TEHMM_SOFT_TIES") && std::atoi(std::getenv("TEHMM_SOFT_TIES")) == 0);
+      lw.soft_ties = soft ? 1 : 0;
       allow_lds(k_vit_lane3<NT, NW, false>, lds);
       hipLaunchKernelGGL((k_vit_lane3<NT, NW, false>), dim3(n_work), dim3(64 * NW), lds, st, iv, lg,
                          (const VitChunks *)lw.d_vc.p, (const VitItems *)lw.d_vi.p, m->N, Wu, (const int *)lw.wk_g.p,
                          (const int *)lw.wk_e.p, n_work, tabs, e0, (const double *)lw.B.p, b->tb.p,
-                         (const double *)nullptr, (const int *)lw.wk_items.p, n_work_dev);
+                         (const double *)nullptr, (const int *)lw.wk_items.p, n_work_dev, lw.soft_ties);
       return;
     }
   }
@@ -1468,7 +1482,7 @@ static void launch_vit_stitch(tehmm_batch *b, const tehmm_model *m, const Interv
                               hipStream_t st) {
   LaneWork &lw = b->lw;
   hipLaunchKernelGGL((k_vit_stitch<NT>), dim3((vc.n + 3) / 4), dim3(256), 0, st, iv, lane_geom(lw), vc,
-                     lane_vit_items(lw), m->N);
+                     lane_vit_items(lw), m->N, lw.soft_ties);
   const char *vl = std::getenv("TEHMM_VIT_RUNS");        // 0: one verification per chunk
   if (vl && std::atoi(vl) == 0)
     (void)hipMemsetAsync(vc.clink, 0, (size_t)vc.n * sizeof(int), st);
@@ -2377,13 +2391,13 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   // orders win from 25 Mb up: mode 3 there, mode 1 below and where one chain dominates.
   const bool big = b->total >= (int64_t)25000000 && 4 * longest <= b->total;
   const int defer_mode = dfs ? std::atoi(dfs) : (big ? 3 : 1);
-  const bool defer_post = vit && postr && vspec && (defer_mode == 1 || defer_mode == 3);
-  const bool split_post = defer_post && defer_mode == 3 && flane && fused_fb && vlane;
+  const bool defer_post = vit && postr && vspec && (defer_mode == 1 || defer_mode == 3 || defer_mode == 5);
+  const bool split_post = defer_post && (defer_mode == 3 || defer_mode == 5) && flane && fused_fb && vlane;
   if (postr) (void)hipEventRecord(b->ev[eP], b->sP);
   // Binade placement on the device (tehmm_place.hip.h; TEHMM_DEVICE_PLACE=0: the host path of rounds 1..3): everything
   // the quantised pass needs besides the gains -- zeroed flags, the argument structs, the tables of all binades -- is
   // put on the stream BEFORE the gain pass, so that nothing but four small kernels separates the two passes.
-  static const bool dev_place_on = !(std::getenv("TEHMM_DEVICE_PLACE") && std::atoi(std::getenv("TEHMM_DEVICE_PLACE")) == 0);
+  const bool dev_place_on = !(std::getenv("TEHMM_DEVICE_PLACE") && std::atoi(std::getenv("TEHMM_DEVICE_PLACE")) == 0);
   const bool dev_place = dev_place_on && vlane && emis_gain;
   if (vspec) {
     vc.iv = sw.iv.p; vc.t0 = sw.t0.p; vc.first = sw.first.p; vc.n = sw.n_chunks; vc.CS = CS;
@@ -2391,6 +2405,7 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     vc.ntie = sw.ntie.p; vc.ties = sw.ties.p; vc.tierows = sw.tierows.p; vc.segmin = sw.segmin.p;
     vc.offend = sw.offend.p; vc.clink = sw.clink.p; vc.clk = sw.clk.p;
     vc.rtarget = sw.rtarget.p; vc.rsel = sw.rsel.p; vc.racc = sw.racc.p; vc.rmn = sw.rmn.p;
+    vc.tsoft = sw.tsoft.p; vc.tpar = sw.tpar.p;
   }
   if (dev_place) {
     hipStream_t st = b->sV;
@@ -2411,47 +2426,59 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
     rc = vit_lane_upload_args(b, vc, st);
     if (rc) return rc;
   }
+  // the emission-row / gain pass of the Viterbi pipeline (a lambda since round 4: mode 5 enqueues it BEHIND the forward pass)
+  auto enqueue_emis_p0 = [&]() -> int {
   if (vlane || glane) {
-    // emission rows of every position, once, item-interleaved (log rows for Viterbi, linear for fwd/bwd)
-    hipStream_t st = b->sV;
-    if (emis_gain) {
+      // emission rows of every position, once, item-interleaved (log rows for Viterbi, linear for fwd/bwd)
+      hipStream_t st = b->sV;
+      if (emis_gain) {
 #define CALL(NT_) launch_emis_gain_lane<NT_>(b, m, iv, em, CS, WuV, ratio, st)
-      TEHMM_NT_DISPATCH(m->NP, CALL)
+        TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
-    } else {
+      } else {
 #define CALL(NT_) launch_emis_lane<NT_>(b, m, iv, em, vlane, flane && !fused_fb, glane, st)
-      TEHMM_NT_DISPATCH(m->NP, CALL)
-#undef CALL
-    }
-    (void)hipEventRecord(b->ev[eV + 4], st);
-    if (flane) {
-      if (!fused_fb) {                                  // (the fused passes compute their own emission rows)
-        (void)hipEventRecord(b->evX[0], st);
-        (void)hipStreamWaitEvent(b->sP, b->evX[0], 0);
-      }
-      (void)hipEventRecord(b->ev[eP + 4], b->sP);
-    }
-  }
-  if (vspec) {
-    // chunk-parallel exact Viterbi: P0 (plain gains) -> binades -> P2 (quantised) -> fix-up chain
-    hipStream_t st = b->sV;
-    if (glane) {
-      if (!emis_gain) {
-#define CALL(NT_) launch_gain_lane<NT_>(b, m, iv, CS, WuV, st)
         TEHMM_NT_DISPATCH(m->NP, CALL)
 #undef CALL
       }
-      if (!dev_place) {
-        gain.resize((size_t)std::max(1, lw.n_groups) * 64);
-        HIPCHK(hipMemcpyAsync(gain.data(), lw.vgain.p, gain.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      (void)hipEventRecord(b->ev[eV + 4], st);
+      if (flane) {
+        if (!fused_fb) {                                  // (the fused passes compute their own emission rows)
+          (void)hipEventRecord(b->evX[0], st);
+          (void)hipStreamWaitEvent(b->sP, b->evX[0], 0);
+        }
+        (void)hipEventRecord(b->ev[eP + 4], b->sP);
       }
-    } else {
-#define CALL(NT_) launch_vit_spec<NT_>(b, m, iv, emg, vc, false, st)
-      TEHMM_NT_DISPATCH(m->NP, CALL)
-#undef CALL
-      gain.resize((size_t)std::max(1, sw.n_chunks));
-      HIPCHK(hipMemcpyAsync(gain.data(), sw.gain.p, gain.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     }
+    if (vspec) {
+      // chunk-parallel exact Viterbi: P0 (plain gains) -> binades -> P2 (quantised) -> fix-up chain
+      hipStream_t st = b->sV;
+      if (glane) {
+        if (!emis_gain) {
+#define CALL(NT_) launch_gain_lane<NT_>(b, m, iv, CS, WuV, st)
+          TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+        }
+        if (!dev_place) {
+          gain.resize((size_t)std::max(1, lw.n_groups) * 64);
+          HIPCHK(hipMemcpyAsync(gain.data(), lw.vgain.p, gain.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        }
+      } else {
+#define CALL(NT_) launch_vit_spec<NT_>(b, m, iv, emg, vc, false, st)
+        TEHMM_NT_DISPATCH(m->NP, CALL)
+#undef CALL
+        gain.resize((size_t)std::max(1, sw.n_chunks));
+        HIPCHK(hipMemcpyAsync(gain.data(), sw.gain.p, gain.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      }
+    }
+    return TEHMM_OK;
+  };
+  // mode 5 (round 4): as mode 3, but the emission + gain pass waits for the forward KERNEL: the forward pass runs alone
+  // (12 ms instead of 17 beside the exact Viterbi chain, or 26 beside the emission kernel), then emission + gain pass,
+  // quantised pass, and the backward half beside the exact chain and the traceback
+  const bool f_first = split_post && defer_mode == 5;
+  if (!f_first) {
+    rc = enqueue_emis_p0();
+    if (rc) return rc;
   }
   auto enqueue_emission = [&]() {
     if (flane && !fused_fb && !vlane && !glane) {
@@ -2570,6 +2597,11 @@ int tehmm_eval_batch(tehmm_model_t *m, tehmm_batch_t *b, int flags, double *vite
   if (split_post) {
     rc = enqueue_posterior(1);
     if (rc) return rc;
+    if (f_first) {
+      (void)hipStreamWaitEvent(b->sV, b->evX[1], 0);       // the forward kernel is through
+      rc = enqueue_emis_p0();
+      if (rc) return rc;
+    }
   } else if (postr && defer_post && flane && fused_fb) {
     // neither do the index records of the fused passes: they only read the observations
     int rcp = TEHMM_OK;

@@ -979,14 +979,19 @@ void k_vit_lane(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItem
 // ------------------------------------------------------------------------------------------
 template <int NT>
 __global__ __launch_bounds__(256) void k_vit_stitch(IntervalTab iv, LaneGeom lg, VitChunks vc, VitItems vi,
-                                                    int N) {
+                                                    int N, int soft = 0) {
+  // soft != 0: the ties the items recorded are SOFT (the pass kept its frame through them, tehmm_lane3.hip.h): rows,
+  // tie rows and minima behind them stay in the segment's frame; only failed item links break it
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= vc.n) return;
   if (vc.e[c] == TEHMM_SPEC_NONE) {
-    if (lane == 0) { vc.ok[c] = 0; vc.ntie[c] = 0; vc.offend[c] = 0.0; }
+    if (lane == 0) { vc.ok[c] = 0; vc.ntie[c] = 0; vc.offend[c] = 0.0; if (vc.tsoft) { vc.tsoft[c] = 0u; vc.tpar[c] = 0u; } }
     return;
   }
+  unsigned softmask = 0u, parmask = 0u;
+  const double uinv = ldexp(1.0, 52 - vc.e[c]);           // 1 / u: offsets are multiples of the grid unit
+  auto odd_mult = [&](double x) { const double q = x * uinv * 0.5; return q != trunc(q); };
   const int id = vc.iv[c];
   const int64_t ct0 = vc.t0[c];
   const int L = lg.L, SUB = vc.CS / L, R = L / TEHMM_VROW;
@@ -1025,7 +1030,7 @@ __global__ __launch_bounds__(256) void k_vit_stitch(IntervalTab iv, LaneGeom lg,
     const int nti = min(vi.ntie[item], TEHMM_LANE_MAXTI);
     const int first_tie = nti > 0 ? vi.ties[item * TEHMM_LANE_MAXTI] : L;
     if (off != 0.0 && lane < NT) {
-      for (int m = 0; m < R && TEHMM_VROW * m + TEHMM_VROW - 1 < first_tie; ++m)
+      for (int m = 0; m < R && (soft || TEHMM_VROW * m + TEHMM_VROW - 1 < first_tie); ++m)
         vc.rows[((int64_t)c * (vc.CS / TEHMM_VROW) + k * R + m) * NT + lane] += off;
     }
     segmin = fmin(segmin, vi.piecemin[item * (TEHMM_LANE_MAXTI + 1)] + off);
@@ -1037,18 +1042,23 @@ __global__ __launch_bounds__(256) void k_vit_stitch(IntervalTab iv, LaneGeom lg,
         }
         if (lane < NT)
           vc.tierows[((int64_t)c * TEHMM_SPEC_MAXT + nT) * NT + lane] =
-              vi.tierows[(item * TEHMM_LANE_MAXTI + i) * NT + lane] + (i == 0 ? off : 0.0);
+              vi.tierows[(item * TEHMM_LANE_MAXTI + i) * NT + lane] + ((i == 0 || soft) ? off : 0.0);
+        if (soft) {
+          softmask |= 1u << nT;
+          if (odd_mult(off)) parmask |= 1u << nT;        // passable for a chain delta of this parity
+        }
       }
       ++nT;
-      segmin = vi.piecemin[item * (TEHMM_LANE_MAXTI + 1) + i + 1];
+      segmin = vi.piecemin[item * (TEHMM_LANE_MAXTI + 1) + i + 1] + (soft ? off : 0.0);
     }
-    off_end = nti > 0 ? 0.0 : off;
+    off_end = (nti > 0 && !soft) ? 0.0 : off;
   }
   if (lane == 0) {
     vc.segmin[(int64_t)c * (TEHMM_SPEC_MAXT + 1) + min(nT, TEHMM_SPEC_MAXT)] = segmin;
     vc.ntie[c] = nT;
     vc.ok[c] = (okc && nT <= TEHMM_SPEC_MAXT) ? 1 : 0;
     vc.offend[c] = off_end;
+    if (vc.tsoft) { vc.tsoft[c] = softmask; vc.tpar[c] = parmask; }
   }
 }
 
@@ -1100,19 +1110,37 @@ __global__ __launch_bounds__(256) void k_vit_links(IntervalTab iv, LaneGeom lg, 
 //   STOP(target, sel, mn)                    chunk with a tie, or the last of its run
 //   PASS(k, s): (target, sel, acc, mn) -> (target, sel, k + acc, min(s, k + mn))     k = clk of the next chunk
 // whose composition is associative and exact (every term is a multiple of the binade's grid unit).
+// Round 4 (soft ties): the scan is kept per parity h of the chain's verified delta on entering the chunk's first
+// segment.  Entry k of a chunk's tie list lets a chain of parity h pass iff it is soft and bit k of tpar equals h;
+// the first entry that does not stops it.  Passing on into the next linked chunk changes the parity by that of the
+// link constant (delta_next = delta + clk).  A chunk is therefore a pair of maps with an outgoing parity each:
 struct VitRunMap {
   int stop;
   int64_t target, sel;
   double acc, mn;
 };
-__device__ __forceinline__ VitRunMap vit_run_compose(const VitRunMap &a, const VitRunMap &b) {   // a after b
-  if (a.stop) return a;
-  VitRunMap r;
-  r.stop = b.stop;
-  r.target = b.target;
-  r.sel = b.sel;
-  r.acc = a.acc + b.acc;
-  r.mn = fmin(a.mn, a.acc + b.mn);
+struct VitRunMap2 {
+  VitRunMap m[2];
+  int hout[2];
+};
+__device__ __forceinline__ VitRunMap2 vit_run_compose(const VitRunMap2 &a, const VitRunMap2 &b) {   // a, then b
+  VitRunMap2 r;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (a.m[h].stop) {
+      r.m[h] = a.m[h];
+      r.hout[h] = 0;
+    } else {
+      const int h2 = a.hout[h];
+      const VitRunMap &bb = h2 ? b.m[1] : b.m[0];
+      r.m[h].stop = bb.stop;
+      r.m[h].target = bb.target;
+      r.m[h].sel = bb.sel;
+      r.m[h].acc = a.m[h].acc + bb.acc;
+      r.m[h].mn = fmin(a.m[h].mn, a.m[h].acc + bb.mn);
+      r.hout[h] = h2 ? b.hout[1] : b.hout[0];
+    }
+  }
   return r;
 }
 __global__ __launch_bounds__(64) void k_vit_runs(VitChunks vc, int n_iv) {
@@ -1120,46 +1148,77 @@ __global__ __launch_bounds__(64) void k_vit_runs(VitChunks vc, int n_iv) {
   const int id = blockIdx.x;
   if (id >= n_iv) return;
   const int64_t c0 = vc.first[id], c1 = vc.first[id + 1];
-  VitRunMap carry{0, 0, 0, 0.0, INFINITY};                 // identity (the interval's last chunk always stops)
+  const int64_t nc = vc.n;
+  VitRunMap2 carry;
+  carry.m[0] = carry.m[1] = VitRunMap{0, 0, 0, 0.0, INFINITY};   // identity (the interval's last chunk always stops)
+  carry.hout[0] = 0;
+  carry.hout[1] = 1;
   for (int64_t hi = c1; hi > c0; hi -= 64) {
     const int64_t c = hi - 64 + lane;                        // lanes ascending in chunk order; tile = [hi - 64, hi)
     const bool in = c >= c0;
-    VitRunMap m{0, 0, 0, 0.0, INFINITY};
+    VitRunMap2 m;
+    m.m[0] = m.m[1] = VitRunMap{0, 0, 0, 0.0, INFINITY};
+    m.hout[0] = 0;
+    m.hout[1] = 1;
     if (in) {
-      const double s0 = vc.segmin[c * (TEHMM_SPEC_MAXT + 1)];
+      const double *sm = vc.segmin + c * (TEHMM_SPEC_MAXT + 1);
       const bool linked_next = c + 1 < c1 && vc.clink[c + 1] != 0;
-      if (vc.ntie[c] > 0) {
-        m = VitRunMap{1, vc.t0[c] + vc.ties[c * TEHMM_SPEC_MAXT], 2 * c, 0.0, s0};
-      } else if (linked_next) {
-        m = VitRunMap{0, 0, 0, vc.clk[c + 1], s0};
-      } else {
-        m = VitRunMap{1, vc.t0[c] + vc.CS, 2 * c + 1, 0.0, s0};
+      const int nt = min(vc.ntie[c], TEHMM_SPEC_MAXT);
+      const unsigned soft = vc.tsoft ? vc.tsoft[c] : 0u, par = vc.tsoft ? vc.tpar[c] : 0u;
+      int kodd = 0;
+      if (linked_next) {
+        const double q = vc.clk[c + 1] * ldexp(1.0, 52 - vc.e[c]) * 0.5;
+        kodd = q != trunc(q);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int kh = -1;
+        double mn = sm[0];
+        for (int k = 0; k < nt; ++k) {
+          if (!((soft >> k) & 1u) || (int)((par >> k) & 1u) != h) { kh = k; break; }
+          mn = fmin(mn, sm[k + 1]);
+        }
+        if (kh >= 0) m.m[h] = VitRunMap{1, vc.t0[c] + vc.ties[c * TEHMM_SPEC_MAXT + kh], 2 * (64 * c + kh), 0.0, mn};
+        else if (linked_next) m.m[h] = VitRunMap{0, 0, 0, vc.clk[c + 1], mn};
+        else m.m[h] = VitRunMap{1, vc.t0[c] + vc.CS, 2 * (64 * c) + 1, 0.0, mn};
+        m.hout[h] = h ^ kodd;
       }
     }
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      VitRunMap o;
-      o.stop = __shfl_down(m.stop, d);
-      o.target = __shfl_down(m.target, d);
-      o.sel = __shfl_down(m.sel, d);
-      o.acc = __shfl_down(m.acc, d);
-      o.mn = __shfl_down(m.mn, d);
+      VitRunMap2 o;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        o.m[h].stop = __shfl_down(m.m[h].stop, d);
+        o.m[h].target = __shfl_down(m.m[h].target, d);
+        o.m[h].sel = __shfl_down(m.m[h].sel, d);
+        o.m[h].acc = __shfl_down(m.m[h].acc, d);
+        o.m[h].mn = __shfl_down(m.m[h].mn, d);
+        o.hout[h] = __shfl_down(m.hout[h], d);
+      }
       if (lane + d < 64) m = vit_run_compose(m, o);
     }
     m = vit_run_compose(m, carry);
     if (in) {
-      vc.rtarget[c] = m.target;
-      vc.rsel[c] = m.sel;
-      vc.racc[c] = m.acc;
-      vc.rmn[c] = m.mn;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        vc.rtarget[h * nc + c] = m.m[h].target;
+        vc.rsel[h * nc + c] = m.m[h].sel;
+        vc.racc[h * nc + c] = m.m[h].acc;
+        vc.rmn[h * nc + c] = m.m[h].mn;
+      }
     }
     // carry = the map of the tile's first chunk (lane 0 is the lowest chunk index of the tile, or out of range
     // in the interval's first tile, after which the loop ends)
-    carry.stop = __shfl(m.stop, 0);
-    carry.target = __shfl(m.target, 0);
-    carry.sel = __shfl(m.sel, 0);
-    carry.acc = __shfl(m.acc, 0);
-    carry.mn = __shfl(m.mn, 0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      carry.m[h].stop = __shfl(m.m[h].stop, 0);
+      carry.m[h].target = __shfl(m.m[h].target, 0);
+      carry.m[h].sel = __shfl(m.m[h].sel, 0);
+      carry.m[h].acc = __shfl(m.m[h].acc, 0);
+      carry.m[h].mn = __shfl(m.m[h].mn, 0);
+      carry.hout[h] = __shfl(m.hout[h], 0);
+    }
   }
 }
 

@@ -67,8 +67,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(lane3_w
 void k_vit_lane3(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitItems *vip, int N, int Wu, const int *wk_g,
                  const int *wk_e, int n_work, const double *__restrict__ tabs, int e0,
                  const double *__restrict__ B, uint8_t *tb, const double *__restrict__ ratios,
-                 const int *__restrict__ wk_items, const int *__restrict__ n_work_dev = nullptr) {
+                 const int *__restrict__ wk_items, const int *__restrict__ n_work_dev = nullptr, int soft_ties = 0) {
   using GEO = Lane3Geom<NT, NW>;
+  // Soft ties (round 4, without segment ratios): a rounding tie does not end the speculation.  The true value of a
+  // state is its frame value plus ONE unknown constant delta (a multiple of the grid unit u); fl(v + b) for a b exactly
+  // between two grid points rounds to the EVEN neighbour, i.e. depends on the parity of v / u.  The pass goes through
+  // the tie assuming delta / u EVEN -- every candidate of a tied output is rounded on its own frame parity -- and
+  // keeps its frame.  The exact chain knows delta when it has verified a chunk: if it is even, the pass was exact
+  // through every tie of the run and the chain jumps over them; if it is odd, the chain lands on the next tie as
+  // before (the tie and the row before it are still recorded), walks it exactly and verifies again behind it.
+  const bool soft = !RATIO && soft_ties != 0;
+  int pbase = 0;                                           // parity of base / u
   constexpr int G = GEO::G, GW = GEO::GW;
   constexpr bool EVEN = G % NW == 0;
   extern __shared__ lane3_d2 lane3_lds[];
@@ -243,6 +252,41 @@ void k_vit_lane3(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitIte
         wn[q] = m6 + 64.0 * (RATIO ? bq + zq1[q] : bq);
         pw |= (~ylo & 63u) << (8 * q);
       }
+      if (!RATIO && soft) {
+        // (rare) tied outputs of this group: the max again with every candidate rounded on its own parity.  Candidate
+        // Y = W[f] + tab[f][o] = 64 (X - base) + index bits; bit 6 of Y / u is the parity of (X - base) / u; a candidate
+        // of odd parity takes the OTHER neighbour of b: bq' = bq + 2 (b - bq), i.e. 128 (b - bq) more in this frame.
+        double tg = 1.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tg = fmin(tg, fabs(fabs(bc[q] - ((bc[q] + M) - M)) - half_u));
+        if (__any(tg == 0.0)) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const double bo = bc[q];
+            const double bq = (bo + M) - M;
+            const bool tq = fabs(fabs(bo - bq) - half_u) == 0.0;
+            if (__any(tq)) {
+              if (tq) {
+                const double dq = 128.0 * (bo - bq);
+                const_f64 *tcol = tab0 + (g * NT) * 4 + q;             // tab[f][o] of this output, f = 0 .. NT - 1
+                double xm = -INFINITY;
+#pragma unroll
+                for (int f = 0; f < NT; ++f) {             // (FULLY unrolled: W[] must stay in registers)
+                  const double Y = W[f] + tcol[f * 4];
+                  const unsigned lo = (unsigned)__double2loint(Y + CM);
+                  const bool odd = (((lo >> 6) & 1u) ^ (unsigned)pbase) != 0u;
+                  xm = fmax(xm, odd ? Y + dq : Y);
+                }
+                const double y = xm + CM;
+                const unsigned ylo = (unsigned)__double2loint(y);
+                const double m6 = __hiloint2double(__double2hiint(y), (int)(ylo & ~63u)) - CM;
+                wn[q] = m6 + 64.0 * bq;
+                pw = (pw & ~(0xffu << (8 * q))) | ((~ylo & 63u) << (8 * q));
+              }
+            }
+          }
+        }
+      }
       if (mine) {
         const int og = og0 + g;
         if (run && official && tb32 && !(TEHMM_L3_EXP & 32)) ((__attribute__((address_space(1))) uint32_t *)tbptr)[g] = pw;
@@ -269,6 +313,7 @@ void k_vit_lane3(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitIte
 #pragma unroll
     for (int j = 0; j < NT; ++j) W[j] = j < N ? 0.0 : -INFINITY;
     base = 0.0;
+    pbase = 0;
     pmin = INFINITY;
   };
   // minimum of a per-wave quantity over the workgroup's waves (rare paths; every wave calls it)
@@ -311,6 +356,41 @@ void k_vit_lane3(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitIte
     }
     pending = tie_prev;
     const int sp = s - 1;
+    auto read_vector = [&]() {
+      const lane3_d2 *src = Wl + (size_t)(k & 1) * (NT / 2) * 64 + lane;
+#pragma unroll
+      for (int jp = 0; jp < NT / 2; ++jp) {
+        const lane3_d2 v = src[jp * 64];
+        W[2 * jp] = v.x;
+        W[2 * jp + 1] = v.y;
+      }
+    };
+    auto record_tie = [&](double pm) {
+      if (run && s - 1 >= 0) {
+        if (nt < TEHMM_LANE_MAXTI && w == 0) {
+          const VitItems *vi = VI();
+          LANE3_GI(lane3_gload(&vi->ties))[item * TEHMM_LANE_MAXTI + nt] = s - 1;
+          lane3_gf64 *tr = LANE3_G(lane3_gload(&vi->tierows)) + (item * TEHMM_LANE_MAXTI + nt) * NT;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) tr[j] = W[j] * 0.015625 + base;
+          LANE3_G(lane3_gload(&vi->piecemin))[item * (TEHMM_LANE_MAXTI + 1) + nt] = pm;
+        }
+        ++nt;
+      }
+    };
+    // soft ties: the tie and the row BEFORE it (still in the registers of the lanes that met it) are recorded, then
+    // those lanes take the new vector too -- computed through the tie on the even-delta hypothesis -- and a new piece
+    // of the SAME frame begins with it.  (Before the re-basing below: the new vector is relative to the old base.)
+    if (soft && tm != 0ull) {                          // (uniform over the workgroup)
+      const double pm = wg_min(pmin);
+      if (pending) {
+        record_tie(pm);
+        read_vector();
+        pmin = wl_prev * 0.015625 + base;
+        bad = bad | (wl_prev <= -(ldexp(1.0, e) - ldexp(1.5, e - 45)));
+      }
+      pending = false;
+    }
     if (((sp + Wu) & (TEHMM_VROW - 1)) == TEHMM_VROW - 1) {
       if (((sp + Wu) & 31) == 31) {
         double mx = W[0];
@@ -320,6 +400,8 @@ void k_vit_lane3(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitIte
 #pragma unroll
           for (int j = 0; j < NT; ++j) W[j] -= mx;
           base += mx * 0.015625;
+          // parity of base / u: mx is a multiple of 64 u, bit 6 of (mx + CM) / u is the parity of mx / (64 u)
+          pbase ^= (int)(((unsigned)__double2loint(mx + CM) >> 6) & 1u);
         } else {
           bad = true;
         }
@@ -331,21 +413,12 @@ void k_vit_lane3(IntervalTab iv, LaneGeom lg, const VitChunks *vcp, const VitIte
         for (int j = 0; j < NT; ++j) row[j] = W[j] * 0.015625 + base;
       }
     }
-    // a tie at s - 1: close the piece with the row of the position before it, restart from zeros behind it
-    if (tm != 0ull) {                                  // (uniform over the workgroup)
+    // hard ties (segment ratios, or soft ties switched off): close the piece with the row of the position before the
+    // tie, restart from zeros behind it
+    if (!soft && tm != 0ull) {                         // (uniform over the workgroup)
       const double pm = wg_min(pmin);
       if (pending) {
-        if (run && s - 1 >= 0) {
-          if (nt < TEHMM_LANE_MAXTI && w == 0) {
-            const VitItems *vi = VI();
-            LANE3_GI(lane3_gload(&vi->ties))[item * TEHMM_LANE_MAXTI + nt] = s - 1;
-            lane3_gf64 *tr = LANE3_G(lane3_gload(&vi->tierows)) + (item * TEHMM_LANE_MAXTI + nt) * NT;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) tr[j] = W[j] * 0.015625 + base;
-            LANE3_G(lane3_gload(&vi->piecemin))[item * (TEHMM_LANE_MAXTI + 1) + nt] = pm;
-          }
-          ++nt;
-        }
+        record_tie(pm);
         restart();
       }
       pending = false;

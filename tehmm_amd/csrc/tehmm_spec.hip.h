@@ -63,13 +63,23 @@ struct VitChunks {
   double *clk;            // lane passes: [chunk] that constant: frame(previous) = frame(this) + clk
   // k_vit_runs: where a verified jump that enters the chunk's FIRST segment ends -- its first tie, or on
   // through the linked chunks behind it (a suffix scan, so that the chain does not walk the run itself)
-  int64_t *rtarget;       // [chunk] position the jump lands on
-  int64_t *rsel;          // [chunk] 2 * chunk' + (0: W row before that chunk's first tie, 1: its last row)
-  double *racc;           // [chunk] sum of clk over the chunks walked: frame(this) = frame(chunk') + racc
-  double *rmn;            // [chunk] lowest live W up to the landing position, in the chunk's frame
+  int64_t *rtarget;       // [2][chunk] position the jump lands on (by the parity of the chain's delta, see below)
+  int64_t *rsel;          // [2][chunk] which recorded row holds the vector before that position (see below)
+  double *racc;           // [2][chunk] sum of clk over the chunks walked: frame(this) = frame(chunk') + racc
+  double *rmn;            // [2][chunk] lowest live W up to the landing position, in the chunk's frame
+  // soft ties (round 4, tehmm_lane3.hip.h): bit k of tsoft[chunk] = entry k of the chunk's tie list is a ROUNDING tie
+  // the quantised pass went through keeping its frame; it did so assuming that the constant between ITS item's frame
+  // and the truth is an even multiple of the grid unit, so the tie is passable for a chain whose verified delta
+  // (relative to the segment frame) has the parity bit k of tpar[chunk] (the parity of the item's offset in the
+  // segment frame).  The other entries are frame breaks (failed item links): every chain stops there.
+  // The run scan (k_vit_runs) is kept per entry parity h: rtarget / rsel / racc / rmn hold [2][chunks] (h * n + chunk);
+  // rsel = 2 * (64 * chunk' + tie index) + (0: the row before that tie, 1: the chunk's last row).
+  unsigned *tsoft, *tpar;
 };
 #define TEHMM_SPEC_MAXT 32
+#ifndef TEHMM_VROW
 #define TEHMM_VROW 16             // spacing of the recorded W rows
+#endif
 
 // wave-wide max / min over the live lanes (fp64, shuffle based: used once per 32 steps)
 __device__ __forceinline__ double wave_max_live(double v, bool live) {
@@ -328,42 +338,68 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
 #endif
         const int64_t g = ct0 + ((cur + TEHMM_FIX_MINSTEP - ct0) / TEHMM_VROW) * TEHMM_VROW + (TEHMM_VROW - 1);
         const int pg = (int)(g - cur);                          // in-block step of the check, 12..27
-        int64_t target = ct0 + vc.CS;
-        double smin = 0.0, lkacc = 0.0;
+        // Where a verified jump lands depends (round 4, soft ties) on the parity h of the verified delta in units of
+        // the grid: entry k of the chunk's tie list is passed iff it is a soft tie of that parity (tsoft / tpar), the
+        // first entry that is not stops the jump; past the chunk end k_vit_runs has walked the linked run for either
+        // parity.  Both plans are laid out before the block's steps; without soft ties they coincide.
+        int64_t target = ct0 + vc.CS, target1 = ct0 + vc.CS;
+        double smin = 0.0, smin1 = 0.0, lkacc = 0.0, lkacc1 = 0.0;
         const double *trow = vc.rows + ((c * (vc.CS / TEHMM_VROW)) + (vc.CS / TEHMM_VROW - 1)) * NT;
+        const double *trow1 = trow;
+        bool spec0 = false, spec1 = false;
         if (spec) {
           const int ntie = vc.ntie[c];
           const int *tl = vc.ties + c * TEHMM_SPEC_MAXT;
           int kseg = ntie;
-          for (int k = 0; k < ntie; ++k) {
-            const int64_t tp = ct0 + tl[k];
-            if (tp > g) { target = tp; trow = vc.tierows + (c * TEHMM_SPEC_MAXT + k) * NT; kseg = k; break; }
-          }
-          if (SEGMIN) {
-            smin = vc.segmin[c * (TEHMM_SPEC_MAXT + 1) + kseg];
-            // the segment may run on through the following chunks (lane passes link them exactly when they
-            // share the binade) up to its first tie or the end of the linked run: k_vit_runs has walked that
-            // run.  lkacc turns values of the landing chunk's first-segment frame into the frame of the check
-            // row's segment.
-            if (target == ct0 + vc.CS && c + 1 < vc.first[id + 1] && vc.clink[c + 1] != 0) {
+          for (int k = 0; k < ntie; ++k)
+            if (ct0 + tl[k] > g) { kseg = k; break; }
+          const unsigned soft = (SEGMIN && vc.tsoft) ? vc.tsoft[c] : 0u, par = (SEGMIN && vc.tsoft) ? vc.tpar[c] : 0u;
+          const int64_t ncn = vc.n;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            int64_t tg = ct0 + vc.CS;
+            const double *tr = vc.rows + ((c * (vc.CS / TEHMM_VROW)) + (vc.CS / TEHMM_VROW - 1)) * NT;
+            double sm = SEGMIN ? vc.segmin[c * (TEHMM_SPEC_MAXT + 1) + kseg] : 0.0, la = 0.0;
+            int kh = -1;
+            for (int k = kseg; k < ntie; ++k) {
+              if (!((soft >> k) & 1u) || (int)((par >> k) & 1u) != h) { kh = k; break; }
+              if (SEGMIN) sm = fmin(sm, vc.segmin[c * (TEHMM_SPEC_MAXT + 1) + k + 1]);
+            }
+            if (kh >= 0) {
+              tg = ct0 + tl[kh];
+              tr = vc.tierows + (c * TEHMM_SPEC_MAXT + kh) * NT;
+            } else if (SEGMIN && c + 1 < vc.first[id + 1] && vc.clink[c + 1] != 0) {
+              // the segment runs on through the following chunks (the lane passes link them exactly when they share
+              // the binade): k_vit_runs has walked that run for the parity the chain arrives with
               const int64_t cn = c + 1;
               const double k1 = vc.clk[cn];
-              const int64_t sel = vc.rsel[cn];
-              lkacc = k1 + vc.racc[cn];
-              smin = fmin(smin, k1 + vc.rmn[cn]);
-              target = vc.rtarget[cn];
-              trow = (sel & 1) ? vc.rows + (((sel >> 1) * (vc.CS / TEHMM_VROW)) + (vc.CS / TEHMM_VROW - 1)) * NT
-                               : vc.tierows + ((sel >> 1) * TEHMM_SPEC_MAXT) * NT;
+              const double qq = k1 * ldexp(1.0, 52 - e) * 0.5;
+              const int h2 = h ^ (qq != trunc(qq) ? 1 : 0);
+              const int64_t sel = vc.rsel[h2 * ncn + cn];
+              la = k1 + vc.racc[h2 * ncn + cn];
+              sm = fmin(sm, k1 + vc.rmn[h2 * ncn + cn]);
+              tg = vc.rtarget[h2 * ncn + cn];
+              const int64_t sc = (sel >> 1) >> 6, sk = (sel >> 1) & 63;
+              tr = (sel & 1) ? vc.rows + ((sc * (vc.CS / TEHMM_VROW)) + (vc.CS / TEHMM_VROW - 1)) * NT
+                             : vc.tierows + (sc * TEHMM_SPEC_MAXT + sk) * NT;
             }
+            if (h == 0) { target = tg; trow = tr; smin = sm; lkacc = la; }
+            else { target1 = tg; trow1 = tr; smin1 = sm; lkacc1 = la; }
           }
-          if (pg >= CPB || g >= ct0 + vc.CS || target <= cur + CPB) spec = false;
+          const bool posok = !(pg >= CPB || g >= ct0 + vc.CS);
+          spec0 = posok && target > cur + CPB;
+          spec1 = posok && target1 > cur + CPB;
+          spec = spec0 || spec1;
         }
-        double wrow = 0.0, wend = 0.0, delta = 0.0;
+        double wrow = 0.0, wend = 0.0, wend1 = 0.0, delta = 0.0;
         bool jump = false;
+        int64_t jtarget = target;
         if (spec) {
-          if (lane == 0) { tent[(it + 1) & 3] = target; *tgen = it + 1; }
+          // (the emission wave prepares the farther landing position; if the parity decides otherwise it prepares again)
+          if (lane == 0) { tent[(it + 1) & 3] = spec0 && (!spec1 || target >= target1) ? target : target1; *tgen = it + 1; }
           wrow = vc.rows[((c * (vc.CS / TEHMM_VROW)) + (g - ct0) / TEHMM_VROW) * NT + jl];
           wend = trow[jl] + lkacc;        // exact: multiples of u inside one binade
+          wend1 = trow1[jl] + lkacc1;
         } else {
           if (lane == 0) { seqpos[(it + 1) & 3] = cur + np; *gen = it + 1; }
         }
@@ -413,11 +449,18 @@ void k_vit_fix(IntervalTab iv, EmisTab em, VitChunks vc, int N, const double *g_
             const double d0 = wave_max_live(both_dead ? -INFINITY : d, live);
             const bool same = !live || both_dead || d == d0;
             const bool inb = !live || both_dead || exp_of(-v) == e + 1;   // 2^e <= |v| < 2^(e+1)
-            const double vlow = SEGMIN ? smin + d0 : wave_min_f64(live && !both_dead ? v : 0.0) - span;
+            // parity of the constant in grid units decides which plan applies
+            const double qh = d0 * ldexp(1.0, 52 - e) * 0.5;
+            const bool hodd = d0 == d0 && d0 > -INFINITY && d0 < INFINITY && qh != trunc(qh);
+            const bool planok = hodd ? spec1 : spec0;
+            const double sminh = hodd ? smin1 : smin;
+            jtarget = hodd ? target1 : target;
+            const double vlow = SEGMIN ? sminh + d0 : wave_min_f64(live && !both_dead ? v : 0.0) - span;
             const bool endok = d0 == d0 && d0 > -INFINITY && exp_of(-vlow) == e + 1;
-            jump = __all(same && inb) && endok;
+            jump = __all(same && inb) && endok && planok;
             delta = d0;
-            if (lane == 0) { seqpos[(it + 1) & 3] = jump ? target : cur + np; *gen = it + 1; }
+            if (hodd) wend = wend1;
+            if (lane == 0) { seqpos[(it + 1) & 3] = jump ? jtarget : cur + np; *gen = it + 1; }
             // verified: the rest of the block belongs to the speculative pass too (its pointer bytes stand)
             if (jump) { nlen = p + 1; break; }
           }

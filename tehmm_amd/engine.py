@@ -249,3 +249,64 @@ class HipBatch(object):
         ms = (ctypes.c_double * 16)()
         n = _lib.load().tehmm_batch_last_timing(self._h, 16, names, ms)
         return {names[i].decode(): ms[i] for i in range(n)}
+
+
+def eval_stream(model, obs, offsets, ratios=None, group_rows=4_000_000, viterbi=True, posterior=True,
+                mask=None, use_ratios=True):
+    """teHmmEval over host-resident intervals with the result transfer hidden behind the evaluation: the intervals
+    are cut into groups of about `group_rows` positions, a worker thread creates and evaluates group g + 1 (H2D of the
+    observations, tehmm_eval_batch) while this thread fetches group g's paths and posteriors over PCIe into pinned
+    host memory -- the reference writes its per-chromosome outputs one after the other as well
+    (bin/teHmmEval.py:312-383).  With the full posterior rows the link is the bound (8 N bytes per position against
+    ~1.4e9 positions/s on the device), so the job takes the transfer time plus one group's evaluation instead of
+    their sum.  mask: fetch the masked posterior sums (teHmmEval.py:270-272) instead of the rows.
+
+    Returns (paths list, posteriors-or-masked-sums list, viterbi_logprob, forward_logprob) in interval order; the
+    per-group arrays are views of pinned blocks."""
+    import threading
+    import queue
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = len(offsets) - 1
+    groups, g0 = [], 0
+    while g0 < n:
+        g1 = g0 + 1
+        while g1 < n and offsets[g1 + 1] - offsets[g0] <= group_rows:
+            g1 += 1
+        groups.append((g0, g1))
+        g0 = g1
+    ready = queue.Queue(maxsize=2)          # at most two evaluated groups wait for their transfer
+
+    def producer():
+        try:
+            for (a, b) in groups:
+                r0, r1 = int(offsets[a]), int(offsets[b])
+                hb = HipBatch(obs[r0:r1], offsets[a:b + 1] - offsets[a], None if ratios is None else ratios[r0:r1])
+                res = model.eval(hb, viterbi=viterbi, posterior=posterior, use_ratios=use_ratios and ratios is not None)
+                ready.put((a, b, hb, res, None))
+        except BaseException as exc:        # (handed to the consumer: it re-raises)
+            ready.put((None, None, None, None, exc))
+
+    th = threading.Thread(target=producer, daemon=True)
+    th.start()
+    paths, posts = [None] * n, [None] * n
+    vlp = np.zeros(n) if viterbi else None
+    flp = np.zeros(n) if posterior else None
+    for _ in groups:
+        a, b, hb, res, exc = ready.get()
+        if exc is not None:
+            th.join()
+            raise exc
+        lo = offsets[a:b + 1] - offsets[a]
+        if viterbi:
+            p = hb.paths()
+            vlp[a:b] = res["viterbi_logprob"]
+            for i in range(a, b):
+                paths[i] = p[int(lo[i - a]):int(lo[i - a + 1])]
+        if posterior:
+            q = hb.posterior_masksum(mask) if mask is not None else hb.posteriors()
+            flp[a:b] = res["forward_logprob"]
+            for i in range(a, b):
+                posts[i] = q[int(lo[i - a]):int(lo[i - a + 1])]
+        hb.close()
+    th.join()
+    return paths, posts, vlp, flp

@@ -18,7 +18,7 @@ def hip():
 
 
 KNOBS = ("TEHMM_P2_SPLIT", "TEHMM_EMIS_SPLIT", "TEHMM_DEVICE_PLACE", "TEHMM_SPEC_CHUNK", "TEHMM_LANE_SUB", "TEHMM_DEFER",
-         "TEHMM_LANE_VIT", "TEHMM_ESTEP_FUSED")
+         "TEHMM_LANE_VIT", "TEHMM_ESTEP_FUSED", "TEHMM_SOFT_TIES")
 
 
 def _noisy_obs(model, total, seed):
@@ -64,6 +64,7 @@ def test_three_wave_passes_bit_exact(monkeypatch, N, ratio):
         rs = np.random.RandomState(N)
         ratios = np.minimum(1 + rs.geometric(1 / 20.0, size=int(offs[-1])), 100) / 20.0
     got = {}
+    monkeypatch.setenv("TEHMM_SOFT_TIES", "0")             # (the one-wave kernel ends a piece at every rounding tie)
     for tag, p2, em in (("split", "1", "1"), ("one", "0", "0")):
         monkeypatch.setenv("TEHMM_P2_SPLIT", p2)
         monkeypatch.setenv("TEHMM_EMIS_SPLIT", em)
@@ -79,6 +80,38 @@ def test_three_wave_passes_bit_exact(monkeypatch, N, ratio):
     assert ts["count:viterbi_chunk_jumps"] > 0
     assert ts["count:viterbi_exact_blocks"] == to["count:viterbi_exact_blocks"]
     assert ts["count:viterbi_chunk_jumps"] == to["count:viterbi_chunk_jumps"]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("N,chunk", [(35, None), (35, "256"), (20, "128"), (50, None), (63, "256")])
+def test_soft_ties_bit_exact_and_fewer_exact_blocks(monkeypatch, N, chunk):
+    """Soft ties (round 4): the quantised pass goes through rounding ties on the even-delta hypothesis and the exact
+    chain passes them when its verified delta has the matching parity.  Paths and scores bit for bit against the oracle
+    -- default and small chunks (every tie, link and parity case at sizes the oracle checks in seconds), low binades where
+    ties come every few dozen positions -- and fewer exact blocks than with every tie ending a piece."""
+    from oracle import oracle
+    from tehmm_amd import synth
+    for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    if chunk is not None:
+        monkeypatch.setenv("TEHMM_SPEC_CHUNK", chunk)
+        monkeypatch.setenv("TEHMM_LANE_SUB", "128" if int(chunk) >= 128 else chunk)
+    model = synth.make_model(N, (3, 5, 4, 30, 250), (4,), seed=70 + N)
+    lens = [260_000, 90_001, 40_000, 5_000]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = _noisy_obs(model, int(offs[-1]), seed=N + 5)
+    got = {}
+    for soft in ("1", "0"):
+        monkeypatch.setenv("TEHMM_SOFT_TIES", soft)
+        got[soft] = _eval(model, obs, offs, viterbi=True, posterior=False)
+    for i in range(len(lens)):
+        sl = slice(int(offs[i]), int(offs[i + 1]))
+        vlp, path = oracle.decode(obs[sl], model.log_probs, model.log_startprob, model.log_transmat)
+        for soft in ("1", "0"):
+            assert_array_equal(got[soft][0][sl], path)
+            assert got[soft][1][i] == vlp
+    assert got["1"][4]["count:viterbi_chunk_jumps"] > 0
+    assert got["1"][4]["count:viterbi_exact_blocks"] < got["0"][4]["count:viterbi_exact_blocks"]
 
 
 @pytest.mark.timeout(900)
@@ -182,3 +215,33 @@ def test_fused_passes_ragged_geometry_vs_oracle(monkeypatch):
     assert_array_equal(res["viterbi_logprob"], ref_vlp)
     assert_allclose(res["forward_logprob"], ref_flp, rtol=1e-9)
     assert_allclose(post, ref_post, rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.timeout(900)
+def test_eval_stream_matches_one_batch(monkeypatch):
+    """engine.eval_stream (interval groups, evaluation of group g + 1 on a worker thread while group g's results cross
+    PCIe) against one evaluation of the whole batch: same paths and scores, posteriors and masked sums at 1e-9."""
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel, eval_stream
+    for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    model = synth.make_model(35, seed=5)
+    lens = [30_000, 1, 12_345, 50_000, 700, 41_000, 8_192]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = synth.sample_obs(model, int(offs[-1]), seed=21, missing=0.03)
+    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, symbols_per_track=model.symbols_per_track)
+    hb = HipBatch(obs, offs)
+    res = hm.eval(hb, viterbi=True, posterior=True)
+    paths, post = hb.paths().copy(), hb.posteriors().copy()
+    hb.close()
+    ps, qs, vlp, flp = eval_stream(hm, obs, offs, group_rows=45_000)
+    mask = (np.arange(35) % 3 == 0).astype(np.float64)
+    _, ms, _, _ = eval_stream(hm, obs, offs, group_rows=45_000, viterbi=False, mask=mask)
+    hm.close()
+    assert_array_equal(vlp, res["viterbi_logprob"])
+    assert_allclose(flp, res["forward_logprob"], rtol=1e-12)
+    for i in range(len(lens)):
+        sl = slice(int(offs[i]), int(offs[i + 1]))
+        assert_array_equal(ps[i], paths[sl])
+        assert_allclose(qs[i], post[sl], rtol=1e-9, atol=1e-15)
+        assert_allclose(ms[i], post[sl] @ mask, rtol=1e-9, atol=1e-15)

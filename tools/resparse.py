@@ -14,7 +14,7 @@ for line in open(sys.argv[1]):
         cur = cur.split("(")[0].replace("void tehmm::", "").replace("tehmm::", "")
         rows[cur] = {}
         continue
-    m = re.search(r":\d+:\d+:\s+([A-Za-z ]+?)(?: \[[\w/]+\])?: (\d+)", line)
+    m = re.search(r":\d+:\d+:(?: remark:)?\s+([A-Za-z ]+?)(?: \[[\w/]+\])?: (\d+)", line)
     if m and cur:
         rows[cur][m.group(1).strip()] = int(m.group(2))
 for k, v in rows.items():
