@@ -95,7 +95,9 @@ static size_t dev_pool_cap() {
   dp.cap[(size_t)d] = cap;
   return cap;
 }
-constexpr size_t kDevPoolMin = (size_t)1 << 20, kDevPoolGran = (size_t)2 << 20;
+// (round 4: every block is pooled, small ones in 4 KB multiples -- hipFree waits for the whole device, and a batch
+//  holds dozens of small tables: destroying one batch while another thread evaluated the next cost the evaluation's time)
+constexpr size_t kDevPoolMin = 1, kDevPoolGran = (size_t)2 << 20, kDevPoolGranSmall = (size_t)4 << 10;
 // gives back the cached blocks of one device (dev >= 0) or of all devices (dev < 0); the caller's device stays current
 static size_t dev_pool_trim(int dev = -1) {
   DevPool &dp = dev_pool();
@@ -126,7 +128,8 @@ static size_t dev_pool_cached(int dev) {
 // *block_bytes = size of the block handed out (what dev_free must be told)
 static hipError_t dev_alloc(void **out, size_t bytes, size_t *block_bytes) {
   const bool pooled = bytes >= kDevPoolMin && dev_pool_cap() > 0;
-  const size_t need = pooled ? (bytes + kDevPoolGran - 1) / kDevPoolGran * kDevPoolGran : bytes;
+  const size_t gran = bytes >= ((size_t)1 << 20) ? kDevPoolGran : kDevPoolGranSmall;
+  const size_t need = pooled ? (bytes + gran - 1) / gran * gran : bytes;
   const int dev = dev_current();
   if (pooled) {
     DevPool &dp = dev_pool();
@@ -153,6 +156,7 @@ static hipError_t dev_alloc(void **out, size_t bytes, size_t *block_bytes) {
   *block_bytes = e == hipSuccess ? need : 0;
   return e;
 }
+static thread_local bool t_streams_synced = false;
 // dev = the device the block was allocated on (DBuf records it)
 static void dev_free(void *p, size_t block_bytes, int dev) {
   if (!p) return;
@@ -160,7 +164,10 @@ static void dev_free(void *p, size_t block_bytes, int dev) {
   if (dev != here) (void)hipSetDevice(dev);
   bool kept = false;
   if (block_bytes >= kDevPoolMin && dev_pool_cap() > 0) {
-    (void)hipDeviceSynchronize();             // what hipFree would do: nothing on the block's device still uses it
+    // what hipFree would do: nothing on the block's device still uses it.  (A batch that is being destroyed has
+    // synchronised its own streams -- the only ones that ever touch its blocks -- and says so: a device-wide wait
+    // would hold this thread until every OTHER batch's kernels have finished, e.g. the next group of eval_stream.)
+    if (!t_streams_synced) (void)hipDeviceSynchronize();
     const size_t cap = dev_pool_cap();
     DevPool &dp = dev_pool();
     std::lock_guard<std::mutex> lk(dp.mu);
@@ -766,6 +773,47 @@ int tehmm_model_destroy(tehmm_model_t *model) {
   return TEHMM_OK;
 }
 
+// ---- streams and events of destroyed batches, kept for the next batch of the same device --------------------------
+namespace {
+struct StreamSet {
+  int dev;
+  hipStream_t sV, sP, sB;
+  hipEvent_t evX[2], ev[16];
+};
+std::mutex g_sset_mu;
+std::vector<StreamSet> g_sset;
+bool stream_set_take(tehmm_batch *b) {
+  const int dev = dev_current();
+  std::lock_guard<std::mutex> lk(g_sset_mu);
+  for (size_t i = 0; i < g_sset.size(); ++i)
+    if (g_sset[i].dev == dev) {
+      const StreamSet ss = g_sset[i];
+      g_sset.erase(g_sset.begin() + (long)i);
+      b->sV = ss.sV; b->sP = ss.sP; b->sB = ss.sB;
+      b->evX[0] = ss.evX[0]; b->evX[1] = ss.evX[1];
+      for (int k = 0; k < 16; ++k) b->ev[k] = ss.ev[k];
+      b->n_ev = 16;
+      return true;
+    }
+  return false;
+}
+bool stream_set_give(tehmm_batch *b) {
+  if (!(b->sV && b->sP && b->sB && b->evX[0] && b->evX[1] && b->n_ev == 16)) return false;
+  StreamSet ss;
+  ss.dev = dev_current();
+  ss.sV = b->sV; ss.sP = b->sP; ss.sB = b->sB;
+  ss.evX[0] = b->evX[0]; ss.evX[1] = b->evX[1];
+  for (int k = 0; k < 16; ++k) ss.ev[k] = b->ev[k];
+  std::lock_guard<std::mutex> lk(g_sset_mu);
+  if (g_sset.size() >= 16) return false;
+  g_sset.push_back(ss);
+  b->sV = b->sP = b->sB = nullptr;
+  b->evX[0] = b->evX[1] = nullptr;
+  b->n_ev = 0;
+  return true;
+}
+}  // namespace
+
 int tehmm_batch_create(int n, const int64_t *offsets, int K, const uint8_t *obs,
                        const double *segRatios, int obs_on_device, tehmm_batch_t **out) {
   if (!out) return fail(TEHMM_ERR_ARG, "tehmm_batch_create: out is NULL");
@@ -812,26 +860,54 @@ int tehmm_batch_create(int n, const int64_t *offsets, int K, const uint8_t *obs,
 
   hipError_t e = hipSuccess;
   auto up = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-  up(b->d_out0.upload(b->h_off.data(), n + 1));
-  up(b->d_pos0.upload(b->h_pos0.data(), n + 1));
-  up(b->d_len.upload(b->h_len.data(), n));
-  up(b->d_chunk0.upload(b->h_chunk0.data(), n + 1));
-  up(b->d_order.upload(b->h_order.data(), n));
-  up(b->d_chunk_iv.upload(chunk_iv.data(), chunk_iv.size()));
+  // the Viterbi pipeline is the longer one: its stream gets the higher dispatch priority so that the
+  // wide posterior kernels fill in around it instead of delaying it
+  // (streams and events of destroyed batches are reused: creating three hardware queues and eighteen events per batch
+  //  is slow, and on this runtime it waits for transfers other threads have in flight)
+  if (!stream_set_take(b)) {
+    int prio_lo = 0, prio_hi = 0;
+    if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->sV, hipStreamNonBlocking, prio_hi);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->sP, hipStreamNonBlocking, prio_lo);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->sB, hipStreamNonBlocking, prio_lo);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->evX[0], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->evX[1], hipEventDisableTiming);
+    for (int i = 0; i < 16 && e == hipSuccess; ++i) {
+      e = hipEventCreate(&b->ev[i]);
+      if (e == hipSuccess) b->n_ev = i + 1;
+    }
+  }
+  // Everything below runs on the batch's OWN stream (round 4): synchronous copies and the legacy default stream are
+  // shared by the whole process, so a batch created while another thread fetched a finished batch's posteriors waited
+  // for that transfer (engine.eval_stream: 20 ms per group), and hipDeviceSynchronize waited for every other batch's
+  // kernels.
+  hipStream_t st = b->sV;
+  auto upa = [&](auto &buf, const auto *h, size_t count) {
+    if (e != hipSuccess) return;
+    e = buf.alloc(count);
+    if (e == hipSuccess && count > 0)
+      e = hipMemcpyAsync(buf.p, h, count * sizeof(*h), hipMemcpyHostToDevice, st);
+  };
+  upa(b->d_out0, b->h_off.data(), (size_t)n + 1);
+  upa(b->d_pos0, b->h_pos0.data(), (size_t)n + 1);
+  upa(b->d_len, b->h_len.data(), (size_t)n);
+  upa(b->d_chunk0, b->h_chunk0.data(), (size_t)n + 1);
+  upa(b->d_order, b->h_order.data(), (size_t)n);
+  upa(b->d_chunk_iv, chunk_iv.data(), chunk_iv.size());
   up(b->obs.alloc((size_t)b->total_pad * b->KP + 16));
   if (segRatios) up(b->ratios.alloc((size_t)b->total_pad + 8));
-  if (e == hipSuccess && b->total_pad > 0) e = hipMemset(b->obs.p, 0, (size_t)b->total_pad * b->KP + 16);
+  if (e == hipSuccess && b->total_pad > 0) e = hipMemsetAsync(b->obs.p, 0, (size_t)b->total_pad * b->KP + 16, st);
   if (e == hipSuccess && segRatios && b->total_pad > 0)
-    e = hipMemset(b->ratios.p, 0, ((size_t)b->total_pad + 8) * sizeof(double));
+    e = hipMemsetAsync(b->ratios.p, 0, ((size_t)b->total_pad + 8) * sizeof(double), st);
   DBuf<uint8_t> stage_obs;
   DBuf<double> stage_r;
   const uint8_t *src = obs;
   const double *rsrc = segRatios;
   if (e == hipSuccess && !obs_on_device && b->total > 0) {
-    up(stage_obs.upload(obs, (size_t)b->total * K));
+    upa(stage_obs, obs, (size_t)b->total * K);
     src = stage_obs.p;
     if (segRatios) {
-      up(stage_r.upload(segRatios, (size_t)b->total));
+      upa(stage_r, segRatios, (size_t)b->total);
       rsrc = stage_r.p;
     }
   }
@@ -841,24 +917,14 @@ int tehmm_batch_create(int n, const int64_t *offsets, int K, const uint8_t *obs,
     for (int i0 = 0; i0 < n; i0 += 32768) {
       const int cnt = std::min(32768, n - i0);
       dim3 grid(grid_for(maxT * b->KP, 256, cnt > 1024 ? 16 : 1024), cnt);
-      hipLaunchKernelGGL(k_repack_obs, grid, dim3(256), 0, 0, cnt, b->d_out0.p + i0, b->d_pos0.p + i0,
+      hipLaunchKernelGGL(k_repack_obs, grid, dim3(256), 0, st, cnt, b->d_out0.p + i0, b->d_pos0.p + i0,
                          b->d_len.p + i0, K, b->KP, src, b->obs.p, rsrc, b->ratios.p);
     }
     up(hipGetLastError());
-    up(hipDeviceSynchronize());
   }
-  // the Viterbi pipeline is the longer one: its stream gets the higher dispatch priority so that the
-  // wide posterior kernels fill in around it instead of delaying it
-  int prio_lo = 0, prio_hi = 0;
-  if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-  if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->sV, hipStreamNonBlocking, prio_hi);
-  if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->sP, hipStreamNonBlocking, prio_lo);
-  if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->sB, hipStreamNonBlocking, prio_lo);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&b->evX[0], hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&b->evX[1], hipEventDisableTiming);
-  for (int i = 0; i < 16 && e == hipSuccess; ++i) {
-    e = hipEventCreate(&b->ev[i]);
-    if (e == hipSuccess) b->n_ev = i + 1;
+  if (b->sV) {                                   // (the staging buffers and host vectors live until here)
+    const hipError_t es = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = es;
   }
   if (e != hipSuccess) {
     tehmm_batch_destroy(b);
@@ -870,12 +936,21 @@ int tehmm_batch_create(int n, const int64_t *offsets, int K, const uint8_t *obs,
 
 int tehmm_batch_destroy(tehmm_batch_t *b) {
   if (!b) return TEHMM_OK;
-  for (int i = 0; i < b->n_ev; ++i) (void)hipEventDestroy(b->ev[i]);
-  if (b->sV) (void)hipStreamDestroy(b->sV);
-  if (b->sP) (void)hipStreamDestroy(b->sP);
-  if (b->sB) (void)hipStreamDestroy(b->sB);
-  for (int i = 0; i < 2; ++i)
-    if (b->evX[i]) (void)hipEventDestroy(b->evX[i]);
+  // the batch's blocks go back to the pool: wait for the streams that use them (all work of a batch is on its own
+  // three streams since round 4), not for the whole device
+  bool synced = b->sV && b->sP && b->sB;
+  if (b->sV) synced = hipStreamSynchronize(b->sV) == hipSuccess && synced;
+  if (b->sP) synced = hipStreamSynchronize(b->sP) == hipSuccess && synced;
+  if (b->sB) synced = hipStreamSynchronize(b->sB) == hipSuccess && synced;
+  struct Guard { bool prev; Guard(bool v) : prev(t_streams_synced) { t_streams_synced = v; } ~Guard() { t_streams_synced = prev; } } guard(synced);
+  if (!(synced && stream_set_give(b))) {
+    for (int i = 0; i < b->n_ev; ++i) (void)hipEventDestroy(b->ev[i]);
+    if (b->sV) (void)hipStreamDestroy(b->sV);
+    if (b->sP) (void)hipStreamDestroy(b->sP);
+    if (b->sB) (void)hipStreamDestroy(b->sB);
+    for (int i = 0; i < 2; ++i)
+      if (b->evX[i]) (void)hipEventDestroy(b->evX[i]);
+  }
   for (int i = 0; i < 2; ++i)
     if (b->stage[i]) (void)hipHostFree(b->stage[i]);
   delete b;
@@ -3037,7 +3112,17 @@ void threaded_copy(void *dst, const void *src, size_t bytes) {
 int d2h(void *dst, const void *src, size_t bytes, tehmm_batch *b) {
   if (bytes == 0) return TEHMM_OK;
   if (is_pinned_host(dst) || bytes < ((size_t)4 << 20)) {
-    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    // (on the batch's own stream: the legacy default stream would serialise this transfer with every other thread's
+    //  synchronous copy -- e.g. the observations of the next batch of engine.eval_stream)
+    // In pieces of 64 MB, each waited for before the next is queued: the copy engine serves its queue in order, and a
+    // multi-GB transfer queued whole kept every other thread's small copies -- the tables of the next batch, the
+    // scalar results of its evaluation -- waiting until it was through (engine.eval_stream: no overlap at all).
+    const size_t piece = (size_t)64 << 20;
+    for (size_t off = 0; off < bytes; off += piece) {
+      const size_t nb = std::min(piece, bytes - off);
+      HIPCHK(hipMemcpyAsync((char *)dst + off, (const char *)src + off, nb, hipMemcpyDeviceToHost, b->sB));
+      HIPCHK(hipStreamSynchronize(b->sB));
+    }
     return TEHMM_OK;
   }
   for (int i = 0; i < 2; ++i)
