@@ -7,7 +7,7 @@
 set -o pipefail
 tag=${1:-r03}
 shift
-parts=${*:-stats traffic estep strong stage}
+parts=${*:-stats traffic estep esteptraffic strong stage pmc}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 mkdir -p "$out"
@@ -36,6 +36,22 @@ if has estep; then
     $B --mode estep --mb 50 --steps 3 --warmup 1 > "$out/${tag}_estep_under_rocprof.json" 2> "$out/${tag}_prof_estep.err" || exit 5
   timeout -k 10 400 $B --mode estep --mb 50 --steps 3 --warmup 1 > "$out/${tag}_bench_estep.json" 2> "$out/${tag}_bench_estep.err" || exit 6
   echo "estep done"
+fi
+if has esteptraffic; then
+  # HBM bytes of one EM iteration (bench.py --mode estep, 50 Mb): FETCH_SIZE / WRITE_SIZE in separate passes
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/${tag}_epmc_$c" -o "$tag" -- \
+      $B --mode estep --mb 50 --steps 1 --warmup 1 --no-cpu-baseline --no-verify > "$out/${tag}_epmc_$c.json" 2> "$out/${tag}_epmc_$c.err" || exit 9
+  done
+  python3 "$root/tools/traffic.py" "$out/${tag}_epmc_FETCH_SIZE" "$out/${tag}_epmc_WRITE_SIZE" \
+    "$(python3 -c "import json;print(json.load(open('$out/${tag}_epmc_FETCH_SIZE.json'))['config']['positions_per_gpu'])")" \
+    "$out/${tag}_estep_traffic.json" || exit 10
+  echo "estep traffic done"
+fi
+if has pmc; then
+  # SQ counters of the headline kernels (three --pmc passes each; kernels serialised by the profiler)
+  STAGES=both timeout -k 10 900 bash "$root/tools/pmc.sh" "${tag}" "k_vit_lane3|k_emis_gain|k_fused_fwd|k_fused_bwd|k_vit_fix|k_tb_" tools/stage_bench.py 100 > "$out/${tag}_pmc.log" 2>&1 || exit 11
+  echo "pmc done"
 fi
 if has strong; then
   timeout -k 10 400 $B --scaling strong --no-extra > "$out/${tag}_bench_strong_1gpu.json" 2> "$out/${tag}_bench_strong.err" || exit 7

@@ -12,7 +12,7 @@ STAGE = [("k_emis_gain_lane", "emission_rows"), ("k_emis_lane", "emission_rows")
          ("k_fb_fix<36, 1", "backward_chain"), ("k_fb_itemlinks", "links"), ("k_fb_stitch", "links"), ("k_fb_runs", "links"),
          ("k_fused_rowindex", "forward_pass"), ("k_repack_obs", "setup_once"), ("k_poison_dead", "backward_chain"),
          ("k_fb_probe", "forward_pass"), ("k_estep_xi", "estep_reduce"), ("k_estep_hist", "estep_reduce"),
-         ("k_fb_lane", "forward_backward_speculate"), ("k_combine_lane", "posterior_combine")]
+         ("k_vit_place", "viterbi_speculate"), ("k_fb_lane", "forward_backward_speculate"), ("k_combine_lane", "posterior_combine")]
 
 
 def last_dispatch(d, counter):
