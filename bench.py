@@ -546,6 +546,11 @@ def extras(args, model, hm, hb, obs, offs, lens, device, torch, mk_model):
 
     # (5) BASELINE configs[3] shape on one GPU: Baum-Welch iterations, 35 states, 12 tracks, 100 kb chunks
     ex["config4_em_iteration"] = em_iterations(50.0, 2, device, torch, None, verify=not args.no_verify)
+    # (5a) the two E-step routes that are NOT chunk-parallel yet (review item 4: today's numbers on the record):
+    #      with segment ratios (sequential k_fb_coop<TRATIO> + k_estep_accum) and 100 states (BaseHMM._do_estep over the
+    #      array-level entry points, [T][N] lattices across PCIe per sequence)
+    ex["estep_with_segment_ratios_35_states"] = estep_other_routes("ratios", torch, device)
+    ex["estep_100_states_array_level"] = estep_other_routes("wide", torch, device)
     return ex
 
 
@@ -574,6 +579,52 @@ def verify_estep(start, ob, o4, n_chunks=4):
     ok = worst <= 1e-6 and abs(lp - ref["logprob"]) <= 1e-9 * abs(ref["logprob"])
     return {"verified": bool(ok), "verified_chunks": int(n_chunks), "statistics_max_rel_err": worst,
             "verify_s": round(time.perf_counter() - t0, 2)}
+
+
+def estep_other_routes(which, torch, device):
+    """One E-step on the routes the chunk-parallel path does not cover (untimed extras)."""
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    if which == "ratios":
+        m4 = synth.make_model(N_STATES, synth.CONFIG4_SYMBOLS, synth.CONFIG4_GAUSSIAN, seed=7)
+        l4 = np.full(50, 100_000, dtype=np.int64)
+        o4 = np.concatenate([[0], np.cumsum(l4)]).astype(np.int64)
+        ob = gen_obs_torch(m4, l4, seed=41, device=device)
+        g = torch.Generator(device=device)
+        g.manual_seed(8)
+        sl = torch.clamp(1 + torch.floor(torch.log1p(-torch.rand(int(o4[-1]), generator=g, device=device, dtype=torch.float64))
+                                         / np.log(1 - 1 / 20.0)), max=100.0)
+        r = (sl / 20.0).contiguous()
+        hm = HipModel(m4.log_transmat, m4.log_startprob, m4.log_probs, symbols_per_track=m4.symbols_per_track)
+        hb = HipBatch(ob.data_ptr(), o4, ratios=r.data_ptr(), device_ptrs=True, K=m4.n_tracks)
+        K, N, S = m4.log_probs.shape
+        st0, tr, ost = np.zeros(N), np.zeros((N, N)), np.zeros((K, N, S))
+        hm.estep(hb, True, st0, tr, ost)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        lp = hm.estep(hb, True, st0, tr, ost)
+        d = time.perf_counter() - t1
+        hb.close()
+        hm.close()
+        return {"value": float(o4[-1]) / d, "unit": "positions/s per E-step", "ms": d * 1e3, "positions": int(o4[-1]),
+                "logprob": lp, "route": "sequential chains per interval (k_fb_coop<TRATIO>) + k_estep_accum"}
+    from tehmm_amd.emission import IndependentMultinomialEmissionModel
+    from tehmm_amd.hmm import MultitrackHmm
+    m5 = synth.make_model(100, (3, 5, 4, 30), (), seed=3)
+    em = IndependentMultinomialEmissionModel(100, list(m5.symbols_per_track))
+    em.logProbs = m5.log_probs.copy()
+    h = MultitrackHmm(em)
+    h.transmat_ = np.exp(m5.log_transmat)
+    h.startprob_ = np.exp(m5.log_startprob)
+    seqs = [synth.sample_obs(m5, 20_000, seed=50 + i) for i in range(3)]
+    stats = h._initialize_sufficient_statistics()
+    h._do_estep(seqs, stats)
+    t1 = time.perf_counter()
+    stats = h._initialize_sufficient_statistics()
+    lp = h._do_estep(seqs, stats)
+    d = time.perf_counter() - t1
+    return {"value": 60_000.0 / d, "unit": "positions/s per E-step", "ms": d * 1e3, "positions": 60_000, "logprob": float(lp),
+            "route": "BaseHMM._do_estep over the array-level entry points (N >= 64)"}
 
 
 def em_iterations(mb, n_iter, device, torch, dist, verify=False):
