@@ -546,11 +546,10 @@ def extras(args, model, hm, hb, obs, offs, lens, device, torch, mk_model):
 
     # (5) BASELINE configs[3] shape on one GPU: Baum-Welch iterations, 35 states, 12 tracks, 100 kb chunks
     ex["config4_em_iteration"] = em_iterations(50.0, 2, device, torch, None, verify=not args.no_verify)
-    # (5a) the two E-step routes that are NOT chunk-parallel yet (review item 4: today's numbers on the record):
-    #      with segment ratios (sequential k_fb_coop<TRATIO> + k_estep_accum) and 100 states (BaseHMM._do_estep over the
-    #      array-level entry points, [T][N] lattices across PCIe per sequence)
-    ex["estep_with_segment_ratios_35_states"] = estep_other_routes("ratios", torch, device)
-    ex["estep_100_states_array_level"] = estep_other_routes("wide", torch, device)
+    # (5a) the E-step where the fused passes do not apply (review item 4): segment ratios at 35 states (5 Mb) and the
+    #      100-state model of configs[4] with ratios (2 Mb), on the item-parallel passes of tehmm_wide_estep.hip.h
+    ex["estep_with_segment_ratios_35_states"] = estep_other_routes("ratios", torch, device, verify=not args.no_verify)
+    ex["estep_100_states_segmented"] = estep_other_routes("wide", torch, device, verify=not args.no_verify)
     return ex
 
 
@@ -581,50 +580,106 @@ def verify_estep(start, ob, o4, n_chunks=4):
             "verify_s": round(time.perf_counter() - t0, 2)}
 
 
-def estep_other_routes(which, torch, device):
-    """One E-step on the routes the chunk-parallel path does not cover (untimed extras)."""
+def estep_other_routes(which, torch, device, verify=True):
+    """One Baum-Welch E-step where the fused passes of tehmm_estep.hip.h do not apply -- segment ratios, 64..128 states --
+    on the item-parallel passes (tehmm_wide_estep.hip.h), with the route of rounds 1-3 timed beside it
+    (`before`: sequential chains for ratios below 64 states, BaseHMM._do_estep over the array-level entry points at
+    100 states) and the first chunks checked against the oracle."""
     from tehmm_amd import synth
     from tehmm_amd.engine import HipBatch, HipModel
     if which == "ratios":
-        m4 = synth.make_model(N_STATES, synth.CONFIG4_SYMBOLS, synth.CONFIG4_GAUSSIAN, seed=7)
-        l4 = np.full(50, 100_000, dtype=np.int64)
-        o4 = np.concatenate([[0], np.cumsum(l4)]).astype(np.int64)
-        ob = gen_obs_torch(m4, l4, seed=41, device=device)
-        g = torch.Generator(device=device)
-        g.manual_seed(8)
-        sl = torch.clamp(1 + torch.floor(torch.log1p(-torch.rand(int(o4[-1]), generator=g, device=device, dtype=torch.float64))
-                                         / np.log(1 - 1 / 20.0)), max=100.0)
-        r = (sl / 20.0).contiguous()
-        hm = HipModel(m4.log_transmat, m4.log_startprob, m4.log_probs, symbols_per_track=m4.symbols_per_track)
-        hb = HipBatch(ob.data_ptr(), o4, ratios=r.data_ptr(), device_ptrs=True, K=m4.n_tracks)
-        K, N, S = m4.log_probs.shape
+        mdl = synth.make_model(N_STATES, synth.CONFIG4_SYMBOLS, synth.CONFIG4_GAUSSIAN, seed=7)
+        lens = np.full(50, 100_000, dtype=np.int64)
+    else:
+        mdl = synth.make_model(100, synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=0)
+        lens = np.full(20, 100_000, dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    total = int(offs[-1])
+    ob = gen_obs_torch(mdl, lens, seed=41, device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(8)
+    sl = torch.clamp(1 + torch.floor(torch.log1p(-torch.rand(total, generator=g, device=device, dtype=torch.float64))
+                                     / np.log(1 - 1 / 20.0)), max=100.0)
+    r = (sl / 20.0).contiguous()
+    K, N, S = mdl.log_probs.shape
+    hm = HipModel(mdl.log_transmat, mdl.log_startprob, mdl.log_probs, symbols_per_track=mdl.symbols_per_track)
+
+    def one(hb, use_r, reps=3):
         st0, tr, ost = np.zeros(N), np.zeros((N, N)), np.zeros((K, N, S))
-        hm.estep(hb, True, st0, tr, ost)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        lp = hm.estep(hb, True, st0, tr, ost)
-        d = time.perf_counter() - t1
-        hb.close()
-        hm.close()
-        return {"value": float(o4[-1]) / d, "unit": "positions/s per E-step", "ms": d * 1e3, "positions": int(o4[-1]),
-                "logprob": lp, "route": "sequential chains per interval (k_fb_coop<TRATIO>) + k_estep_accum"}
-    from tehmm_amd.emission import IndependentMultinomialEmissionModel
-    from tehmm_amd.hmm import MultitrackHmm
-    m5 = synth.make_model(100, (3, 5, 4, 30), (), seed=3)
-    em = IndependentMultinomialEmissionModel(100, list(m5.symbols_per_track))
-    em.logProbs = m5.log_probs.copy()
-    h = MultitrackHmm(em)
-    h.transmat_ = np.exp(m5.log_transmat)
-    h.startprob_ = np.exp(m5.log_startprob)
-    seqs = [synth.sample_obs(m5, 20_000, seed=50 + i) for i in range(3)]
-    stats = h._initialize_sufficient_statistics()
-    h._do_estep(seqs, stats)
-    t1 = time.perf_counter()
-    stats = h._initialize_sufficient_statistics()
-    lp = h._do_estep(seqs, stats)
-    d = time.perf_counter() - t1
-    return {"value": 60_000.0 / d, "unit": "positions/s per E-step", "ms": d * 1e3, "positions": 60_000, "logprob": float(lp),
-            "route": "BaseHMM._do_estep over the array-level entry points (N >= 64)"}
+        lp = hm.estep(hb, use_r, st0, tr, ost)
+        best = None
+        for _ in range(reps):
+            st0[:], tr[:], ost[:] = 0.0, 0.0, 0.0
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            lp = hm.estep(hb, use_r, st0, tr, ost)
+            d = time.perf_counter() - t1
+            best = d if best is None else min(best, d)
+        return best, lp, hb.timing(), (st0, tr, ost)
+
+    hb = HipBatch(ob.data_ptr(), offs, ratios=r.data_ptr(), device_ptrs=True, K=K)
+    d, lp, tm, got = one(hb, True)
+    out = {"value": total / d, "unit": "positions/s per E-step", "ms": d * 1e3, "positions": total, "states": N,
+           "segment_ratios": True, "logprob": lp, "kernel_ms": tm,
+           "route": "item-parallel passes k_wide_fwd / k_wide_bwd<ESTEP> + k_wide_estep_xi / k_wide_estep_rows",
+           "arithmetic": "f64 recurrences and sums; alpha', gamma, wz rows kept as f32"}
+    if which == "ratios":
+        os.environ["TEHMM_ESTEP_WIDE"] = "0"
+        try:
+            d0, lp0, _, _ = one(hb, True, reps=1)
+        finally:
+            del os.environ["TEHMM_ESTEP_WIDE"]
+        out["before"] = {"ms": d0 * 1e3, "value": total / d0, "logprob": lp0,
+                         "route": "sequential chains per interval (k_fb_coop<TRATIO>) + k_estep_accum"}
+    else:
+        d1, lp1, tm1, _ = one(hb, False)
+        out["without_ratios"] = {"ms": d1 * 1e3, "value": total / d1, "logprob": lp1, "kernel_ms": tm1}
+    hb.close()
+    if verify:
+        from oracle import oracle
+        nv = 2 if which == "ratios" else 1
+        nrow = 100_000 if which == "ratios" else 30_000          # (the oracle's xi pass is N^2 exponentials per position)
+        sub = np.concatenate([ob[int(offs[i]):int(offs[i]) + nrow].cpu().numpy() for i in range(nv)])
+        rsub = np.concatenate([r[int(offs[i]):int(offs[i]) + nrow].cpu().numpy() for i in range(nv)])
+        so = np.arange(nv + 1, dtype=np.int64) * nrow
+        hbv = HipBatch(sub, so, rsub)
+        st0, tr, ost = np.zeros(N), np.zeros((N, N)), np.zeros((K, N, S))
+        lpv = hm.estep(hbv, True, st0, tr, ost)
+        ran = "estep_emission_rows" in hbv.timing()
+        hbv.close()
+        t0 = time.perf_counter()
+        ref = oracle.estep([sub[int(so[i]):int(so[i + 1])] for i in range(nv)], mdl.log_probs, mdl.log_startprob,
+                           mdl.log_transmat, 1.0, [rsub[int(so[i]):int(so[i + 1])] for i in range(nv)])
+
+        def rel(a, b, floor):
+            return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
+        worst = max(rel(st0, ref["start"], 1e-12), rel(tr, ref["trans"], 1e-6), rel(ost, ref["obs"], 1e-6))
+        out.update({"verified": bool(ran and worst <= 1e-6 and abs(lpv - ref["logprob"]) <= 1e-9 * abs(ref["logprob"])),
+                    "verified_positions": int(so[-1]), "statistics_max_rel_err": worst,
+                    "verify_s": round(time.perf_counter() - t0, 2)})
+    if which != "ratios":
+        # what rounds 1-3 ran at this size: the reference's per-sequence loop over the array-level entry points
+        from tehmm_amd.emission import IndependentMultinomialEmissionModel
+        from tehmm_amd.hmm import MultitrackHmm
+        em = IndependentMultinomialEmissionModel(N, list(mdl.symbols_per_track))
+        em.logProbs = mdl.log_probs.copy()
+        h = MultitrackHmm(em)
+        h.transmat_ = np.exp(mdl.log_transmat)
+        h.startprob_ = np.exp(mdl.log_startprob)
+        seqs = [ob[int(offs[i]):int(offs[i]) + 20_000].cpu().numpy() for i in range(3)]
+        os.environ["TEHMM_ESTEP_WIDE"] = "0"
+        try:
+            h._do_estep(seqs, h._initialize_sufficient_statistics())
+            t1 = time.perf_counter()
+            h._do_estep(seqs, h._initialize_sufficient_statistics())
+            d0 = time.perf_counter() - t1
+        finally:
+            del os.environ["TEHMM_ESTEP_WIDE"]
+        out["before"] = {"ms": d0 * 1e3, "value": 60_000.0 / d0, "positions": 60_000, "segment_ratios": False,
+                         "route": "BaseHMM._do_estep over the array-level entry points"}
+    hm.close()
+    del ob, r
+    return out
 
 
 def em_iterations(mb, n_iter, device, torch, dist, verify=False):

@@ -175,7 +175,13 @@ int tehmm_write_bed(const char *path, int append, const char *chrom, int64_t n, 
  * MultitrackHmm._accumulate_sufficient_statistics, hmm.py:545-574): accumulates INTO the host
  * arrays start[N], trans[N][N], obsStats[K][N][S] (the caller initialises them, e.g. with
  * emission.initStats' fudge) and returns the summed forward log-likelihood.  use_ratios: apply
- * the batch's segRatios everywhere, as fit does for segmented TrackTables. */
+ * the batch's segRatios everywhere, as fit does for segmented TrackTables (emission rows scaled,
+ * emission.py:195-196; lt[j][j] (r - 1) in the recurrences, _hmm.pyx:131-140; ratio-weighted posteriors in
+ * the histograms, _emission.pyx:183-190; the diagonal term of _log_sum_lneta, _hmm.pyx:94-99).
+ * N <= 128.  Below 64 states without ratios: the chunk-parallel fused passes with exact chains; with ratios,
+ * and at 64..128 states: the item-parallel passes (warm-up + verified links); what those do not take (rows no
+ * state can emit, links that never verify) runs on sequential kernels below 64 states and returns
+ * TEHMM_ERR_UNSUPPORTED at 64 and above (the array-level entry points then serve the reference's own loop). */
 int tehmm_estep_batch(tehmm_model_t *model, tehmm_batch_t *batch, int use_ratios, double *start,
                       double *trans, double *obsStats, double *logprob_sum);
 

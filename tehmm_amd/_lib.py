@@ -83,7 +83,7 @@ _lib = None
 
 
 class TeHmmHipError(RuntimeError):
-    pass
+    code = 0                      # the TEHMM_ERR_* code of the failed call (-3: TEHMM_ERR_UNSUPPORTED)
 
 
 def load():
@@ -106,8 +106,10 @@ def load():
 def check(rc, what=""):
     if rc != 0:
         msg = load().tehmm_last_error()
-        raise TeHmmHipError("%s failed (%d): %s" % (what or "tehmm call", rc,
-                                                     msg.decode() if msg else "?"))
+        err = TeHmmHipError("%s failed (%d): %s" % (what or "tehmm call", rc,
+                                                    msg.decode() if msg else "?"))
+        err.code = int(rc)
+        raise err
 
 
 def device_count():

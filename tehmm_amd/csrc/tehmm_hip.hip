@@ -9,6 +9,7 @@
 #include "tehmm_aux.hip.h"
 #include "tehmm_fused.hip.h"
 #include "tehmm_estep.hip.h"
+#include "tehmm_wide_estep.hip.h"
 #include "tehmm_wide.hip.h"
 
 #include <algorithm>
@@ -378,6 +379,14 @@ struct WideWork {
   DBuf<int64_t> item_t0, ifirst;
   DBuf<double> E, ms, pre_f, end_f, pre_b, end_b, SL, lr;
   DBuf<float> AL;
+  // E-step on these passes (tehmm_wide_estep.hip.h): gamma / wz rows in the alpha' layout, the row table of the
+  // gamma product, per-writer partial sums
+  DBuf<float> GAM, WZ;
+  bool al_zeroed = false;
+  WideRows h_rows;
+  DBuf<WideRows> d_rows;
+  uint64_t rows_model = 0;
+  DBuf<double> part_xi, part_rows;
   // chunk-parallel exact Viterbi (k_vit_wide_spec / k_vit_wide_fix)
   DBuf<double> BL;                 // log emission rows [internal position][128]
   DBuf<double> rows2;              // recorded rows of the second tie hypothesis
@@ -1917,14 +1926,44 @@ static void launch_wide_passes(tehmm_batch *b, const tehmm_model *m, const Inter
                      (const double *)w.E.p, (const float *)w.AL.p, b->post.p, w.pre_b.p, w.end_b.p);
 }
 
+// the E-step form (tehmm_wide_estep.hip.h): the backward pass leaves gamma / wz rows instead of posteriors
+template <int NPW>
+static void launch_wide_passes_estep(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const LaneGeom &lg, int Wu,
+                                     hipStream_t st, hipEvent_t mid) {
+  WideWork &w = b->ww;
+  const size_t lds = WideGeom<NPW>::FRAG_BYTES;
+  allow_lds(k_wide_fwd<NPW>, lds);
+  allow_lds(k_wide_bwd<NPW, true>, lds);
+  const dim3 grid((unsigned)std::max(1, w.n_groups));
+  hipLaunchKernelGGL((k_wide_fwd<NPW>), grid, dim3(256), lds, st, iv, lg, m->N, m->NP, Wu, (const double *)m->A.p,
+                     (const double *)m->pi.p, (const double *)w.E.p, (const double *)w.ms.p, w.AL.p, w.pre_f.p, w.end_f.p,
+                     w.SL.p);
+  (void)hipEventRecord(mid, st);
+  hipLaunchKernelGGL((k_wide_bwd<NPW, true>), grid, dim3(256), lds, st, iv, lg, m->N, m->NP, Wu, (const double *)m->A.p,
+                     (const double *)w.E.p, (const float *)w.AL.p, (double *)nullptr, w.pre_b.p, w.end_b.p, w.GAM.p, w.WZ.p);
+}
+
 // One attempt of the chunk-parallel posterior with warm-up Wu, enqueued on st: passes, link checks, and the flags
 // (impossible rows, failed links) on their way to pinned host memory.
-static int wide_post_attempt(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, int Wu, hipStream_t st, hipEvent_t mid) {
+static int wide_post_attempt(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, int Wu, hipStream_t st, hipEvent_t mid,
+                             bool estep = false) {
   WideWork &w = b->ww;
   LaneGeom lg;
   lg.item_iv = w.item_iv.p; lg.item_t0 = w.item_t0.p; lg.ifirst = w.ifirst.p;
   lg.n_items = w.n_items; lg.n_groups = w.n_groups; lg.L = w.L;
   const int NPW = w.NPW;
+  if (estep) {
+    switch (NPW) {
+      case 16: launch_wide_passes_estep<16>(b, m, iv, lg, Wu, st, mid); break;
+      case 32: launch_wide_passes_estep<32>(b, m, iv, lg, Wu, st, mid); break;
+      case 48: launch_wide_passes_estep<48>(b, m, iv, lg, Wu, st, mid); break;
+      case 64: launch_wide_passes_estep<64>(b, m, iv, lg, Wu, st, mid); break;
+      case 80: launch_wide_passes_estep<80>(b, m, iv, lg, Wu, st, mid); break;
+      case 96: launch_wide_passes_estep<96>(b, m, iv, lg, Wu, st, mid); break;
+      case 112: launch_wide_passes_estep<112>(b, m, iv, lg, Wu, st, mid); break;
+      default: launch_wide_passes_estep<128>(b, m, iv, lg, Wu, st, mid); break;
+    }
+  } else
   switch (NPW) {
     case 80: launch_wide_passes<80>(b, m, iv, lg, Wu, st, mid); break;
     case 96: launch_wide_passes<96>(b, m, iv, lg, Wu, st, mid); break;
@@ -1976,30 +2015,18 @@ static int posterior_wide_finish(tehmm_batch *b, const tehmm_model *m, const Int
   return TEHMM_OK;
 }
 
-// Chunk-parallel posterior for 64 <= N <= 128: geometry, emission rows and the first attempt are ENQUEUED here
-// (*pending = true; nothing enqueued otherwise: short batches, TEHMM_WIDE_CP=0); posterior_wide_finish delivers the
-// verdict, so the exact Viterbi of the same evaluation can be enqueued in between and share the GPU with the passes.
-static int posterior_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em, hipStream_t st,
-                             hipEvent_t mid, bool *pending, const double *log_rows = nullptr) {
-  *pending = false;
-  const char *ws = std::getenv("TEHMM_WIDE_CP");
-  if (ws && std::atoi(ws) == 0) return TEHMM_OK;
-  if (m->N < 64 || m->N > 128 || b->total < 4096) return TEHMM_OK;
-  static const int sizes[] = {80, 96, 112, 128};
-  int NPW = 128;
-  for (int sz : sizes)
-    if (m->N <= sz) { NPW = sz; break; }
+// Item geometry and workspaces of the item-parallel passes for (NPW, L); *fits = false: not enough device memory
+// (nothing changed).  The alpha' rows are (re)allocated here: al_zeroed tells the E-step whether the slots no pass
+// writes have been cleared since.
+static int wide_geometry(tehmm_batch *b, int NPW, int L, bool *fits) {
   WideWork &w = b->ww;
-  if (!w.h_flags) HIPCHK(hipHostMalloc((void **)&w.h_flags, 64, hipHostMallocDefault));
-  // item length: enough items to give every SIMD a tile (1024 tiles of 16 items), 64 <= L <= 512, multiple of 32
-  int L = (int)std::min<int64_t>(512, std::max<int64_t>(64, (b->total / (16 * 1024) + 31) & ~31));
-  if (const char *ls = std::getenv("TEHMM_WIDE_SUB")) L = std::max(32, (std::atoi(ls) + 31) & ~31);
+  *fits = true;
   if (w.L != L || w.NPW != NPW || !w.item_iv.p) {
     {
       // emission rows (8 NPW bytes per position) + float alpha' rows (4 NPW): the sequential kernels need neither
       size_t free_b = 0, total_b = 0;
       HIPCHK(dev_mem_info(&free_b, &total_b));
-      if ((double)b->total * NPW * 12.5 + (double)(b->total / L + b->n + 64) * NPW * 40.0 > 0.9 * (double)free_b) return TEHMM_OK;
+      if ((double)b->total * NPW * 12.5 + (double)(b->total / L + b->n + 64) * NPW * 40.0 > 0.9 * (double)free_b) { *fits = false; return TEHMM_OK; }
     }
     std::vector<int> h_iv;
     std::vector<int64_t> h_t0, h_first((size_t)b->n + 1, 0);
@@ -2027,6 +2054,35 @@ static int posterior_wide_cp(tehmm_batch *b, const tehmm_model *m, const Interva
     HIPCHK(w.SL.alloc(ni));
     HIPCHK(w.lr.alloc(ni));
     HIPCHK(w.flags.alloc(4));
+    w.al_zeroed = false;
+    w.GAM.release();
+    w.WZ.release();
+  }
+  return TEHMM_OK;
+}
+
+// Chunk-parallel posterior for 64 <= N <= 128: geometry, emission rows and the first attempt are ENQUEUED here
+// (*pending = true; nothing enqueued otherwise: short batches, TEHMM_WIDE_CP=0); posterior_wide_finish delivers the
+// verdict, so the exact Viterbi of the same evaluation can be enqueued in between and share the GPU with the passes.
+static int posterior_wide_cp(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em, hipStream_t st,
+                             hipEvent_t mid, bool *pending, const double *log_rows = nullptr) {
+  *pending = false;
+  const char *ws = std::getenv("TEHMM_WIDE_CP");
+  if (ws && std::atoi(ws) == 0) return TEHMM_OK;
+  if (m->N < 64 || m->N > 128 || b->total < 4096) return TEHMM_OK;
+  static const int sizes[] = {80, 96, 112, 128};
+  int NPW = 128;
+  for (int sz : sizes)
+    if (m->N <= sz) { NPW = sz; break; }
+  WideWork &w = b->ww;
+  if (!w.h_flags) HIPCHK(hipHostMalloc((void **)&w.h_flags, 64, hipHostMallocDefault));
+  // item length: enough items to give every SIMD a tile (1024 tiles of 16 items), 64 <= L <= 512, multiple of 32
+  int L = (int)std::min<int64_t>(512, std::max<int64_t>(64, (b->total / (16 * 1024) + 31) & ~31));
+  if (const char *ls = std::getenv("TEHMM_WIDE_SUB")) L = std::max(32, (std::atoi(ls) + 31) & ~31);
+  {
+    bool fits = true;
+    if (int rcg = wide_geometry(b, NPW, L, &fits)) return rcg;
+    if (!fits) return TEHMM_OK;
   }
   LaneGeom lg;
   lg.item_iv = w.item_iv.p; lg.item_t0 = w.item_t0.p; lg.ifirst = w.ifirst.p;
@@ -3676,13 +3732,212 @@ static int estep_fused(tehmm_model_t *m, tehmm_batch_t *b, double *dev_stats, do
   return TEHMM_OK;
 }
 
+// ---- E-step on the item-parallel passes of tehmm_wide.hip.h (tehmm_wide_estep.hip.h): 64 <= N <= 128 states, and
+// segment ratios at any N <= 128 ---------------------------------------------------------------------------------
+static int wide_estep_npw(int N) {
+  static const int sizes[] = {16, 32, 48, 64, 80, 96, 112, 128};
+  for (int sz : sizes)
+    if (N <= sz) return sz;
+  return 0;
+}
+
+static bool estep_wide_wanted(const tehmm_model *m, const tehmm_batch *b, bool ratio) {
+  int mode = 1;                                     // 0: off, 1: where the fused passes do not apply, 2: everywhere
+  if (const char *s = std::getenv("TEHMM_ESTEP_WIDE")) mode = std::atoi(s);
+  if (mode == 0 || m->N > 128 || b->total < 1024) return false;
+  if (mode == 1 && !(ratio || m->N >= 64)) return false;
+  if (m->R + 2 > TEHMM_ESTEP_MAXRT * 16 || m->K > 255) return false;
+  return true;
+}
+
+template <int NPW>
+static int launch_wide_estep_reduce(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const LaneGeom &lg, bool ratio,
+                                    double *dev_stats, hipStream_t st) {
+  WideWork &w = b->ww;
+  using G = WideEstepGeom<NPW>;
+  const int64_t n_tiles = ((int64_t)w.n_items + 15) / 16;
+  double *gC = dev_stats + stats_off_C(m->NP), *gD = dev_stats + stats_off_D(m->NP), *gstart = dev_stats + stats_off_start(),
+         *gstat = dev_stats + stats_off_stat(m->NP);
+  // xi: two workgroups per CU at most; gamma product: one item tile per workgroup at a time
+  const int gxm = (int)std::max<int64_t>(1, std::min<int64_t>((n_tiles + G::TPW - 1) / G::TPW, 512));
+  HIPCHK(w.part_xi.ensure((size_t)gxm * G::TPW * NPW * NPW));
+  const int nrt = w.h_rows.n_rt;
+  const int gxr = (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles, 512));
+  HIPCHK(w.part_rows.ensure((size_t)gxr * nrt * 16 * NPW));
+  // the two products are independent: the gamma product runs on its own stream next to the xi product
+  (void)hipEventRecord(b->evX[0], st);
+  (void)hipStreamWaitEvent(b->sB, b->evX[0], 0);
+  if (ratio)
+    hipLaunchKernelGGL((k_wide_estep_rows<NPW, true>), dim3(gxr, (nrt + 3) / 4), dim3(256), 0, b->sB, iv, lg,
+                       (const WideRows *)w.d_rows.p, b->KP, (const uint8_t *)b->obs.p, (const double *)b->ratios.p,
+                       (const float *)w.GAM.p, w.part_rows.p);
+  else
+    hipLaunchKernelGGL((k_wide_estep_rows<NPW, false>), dim3(gxr, (nrt + 3) / 4), dim3(256), 0, b->sB, iv, lg,
+                       (const WideRows *)w.d_rows.p, b->KP, (const uint8_t *)b->obs.p, (const double *)nullptr,
+                       (const float *)w.GAM.p, w.part_rows.p);
+  hipLaunchKernelGGL(k_wide_fold_rows, dim3((nrt * 16 * m->N + 255) / 256), dim3(256), 0, b->sB, (const double *)w.part_rows.p,
+                     gxr, m->N, NPW, m->NP, (const WideRows *)w.d_rows.p, gstat, gstart, gD);
+  (void)hipEventRecord(b->evX[1], b->sB);
+  hipLaunchKernelGGL((k_wide_estep_xi<NPW>), dim3(gxm), dim3(256), 0, st, iv, lg, (const float *)w.AL.p, (const float *)w.WZ.p,
+                     w.part_xi.p);
+  hipLaunchKernelGGL(k_wide_fold_xi, dim3((m->N * m->N + 255) / 256), dim3(256), 0, st, (const double *)w.part_xi.p, gxm * G::TPW,
+                     m->N, NPW, m->NP, gC);
+  (void)hipStreamWaitEvent(st, b->evX[1], 0);
+  return TEHMM_OK;
+}
+
+// returns TEHMM_OK and *done = true when the path ran; *done = false: the caller falls back
+static int estep_wide(tehmm_model_t *m, tehmm_batch_t *b, bool ratio, double *dev_stats, double *lp_out, int *dead_out, bool *done) {
+  *done = false;
+  if (!estep_wide_wanted(m, b, ratio)) return TEHMM_OK;
+  const int NPW = wide_estep_npw(m->N);
+  if (NPW <= 0) return TEHMM_OK;
+  WideWork &w = b->ww;
+  if (!w.h_flags) HIPCHK(hipHostMalloc((void **)&w.h_flags, 64, hipHostMallocDefault));
+  // item length: as posterior_wide_cp (enough items to give every SIMD a tile, 64 <= L <= 512, multiple of 32)
+  int L = (int)std::min<int64_t>(512, std::max<int64_t>(64, (b->total / (16 * 1024) + 31) & ~31));
+  if (const char *ls = std::getenv("TEHMM_WIDE_SUB")) L = std::max(32, (std::atoi(ls) + 31) & ~31);
+  if (!(w.GAM.p && w.L == L && w.NPW == NPW)) {
+    // emission rows + three float rows per position must fit
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(dev_mem_info(&free_b, &total_b));
+    if ((double)b->total * NPW * 22.0 + (double)(b->total / L + b->n + 64) * NPW * 40.0 > 0.85 * (double)free_b) return TEHMM_OK;
+  }
+  {
+    bool fits = true;
+    if (int rcg = wide_geometry(b, NPW, L, &fits)) return rcg;
+    if (!fits) return TEHMM_OK;
+  }
+  const size_t na = (size_t)std::max(1, w.n_groups) * 64 * L * (NPW / 4) * 4;
+  if (!w.GAM.p) {
+    HIPCHK(w.GAM.alloc(na));
+    HIPCHK(w.WZ.alloc(na));
+    w.al_zeroed = false;
+  }
+  if (!w.al_zeroed) {       // slots no pass writes (beyond an item's end) are read by the reductions: zero once
+    HIPCHK(hipMemset(w.AL.p, 0, na * sizeof(float)));
+    HIPCHK(hipMemset(w.GAM.p, 0, na * sizeof(float)));
+    HIPCHK(hipMemset(w.WZ.p, 0, na * sizeof(float)));
+    w.al_zeroed = true;
+  }
+  if (!b->fwd_lp.p || !b->dead.p) {
+    HIPCHK(b->fwd_lp.alloc((size_t)b->n + 1));
+    HIPCHK(b->dead.alloc((size_t)b->n + 1));
+    if (!b->first_good.p) HIPCHK(b->first_good.alloc((size_t)b->n + 1));
+  }
+  if (w.rows_model != m->uid || !w.d_rows.p) {
+    WideRows &wr = w.h_rows;
+    for (int i = 0; i < TEHMM_ESTEP_MAXRT * 16; ++i) { wr.info[i] = -1; wr.grow[i] = 0; }
+    int row = 0;
+    wr.info[row++] = TEHMM_WIDE_ROW_START;
+    wr.info[row++] = TEHMM_WIDE_ROW_DIAG;
+    for (int k = 0; k < m->K; ++k)
+      for (int sy = 0; sy < m->rowcnt[k]; ++sy, ++row) {
+        wr.info[row] = (k & 255) | (sy << 8);
+        wr.grow[row] = m->rowbase[k] + sy;
+      }
+    wr.n_rt = (row + 15) / 16;
+    HIPCHK(w.d_rows.upload(&wr, 1));
+    w.rows_model = m->uid;
+  }
+  IntervalTab iv;
+  EmisTab em;
+  fill_tabs(m, b, iv, em, ratio);     // fit applies the ratios to emissions too (basehmm.py:510)
+  const EmisTab emg = without_lds_tables(em);
+  LaneGeom lg;
+  lg.item_iv = w.item_iv.p; lg.item_t0 = w.item_t0.p; lg.ifirst = w.ifirst.p;
+  lg.n_items = w.n_items; lg.n_groups = w.n_groups; lg.L = L;
+  hipStream_t st = b->sP;
+  b->tnames.clear();
+  b->tpairs.clear();
+  b->tms.clear();
+  (void)hipEventRecord(b->ev[10], st);
+  HIPCHK(hipMemsetAsync(w.flags.p, 0, 4 * sizeof(int), st));
+  if (ratio)
+    hipLaunchKernelGGL((k_wide_emis_fit<true>), dim3((w.n_items + 3) / 4), dim3(256), 0, st, iv, emg, lg, m->N, NPW, m->NP,
+                       (const double *)m->lt.p, (const double *)b->ratios.p, w.E.p, w.ms.p, w.flags.p);
+  else
+    hipLaunchKernelGGL((k_wide_emis_fit<false>), dim3((w.n_items + 3) / 4), dim3(256), 0, st, iv, emg, lg, m->N, NPW, m->NP,
+                       (const double *)m->lt.p, (const double *)nullptr, w.E.p, w.ms.p, w.flags.p);
+  (void)hipEventRecord(b->ev[9], st);
+  // warm-up: what the last E-step with this model handle needed (the parameters move a little per iteration; the links
+  // are verified whatever the guess), 128 positions to begin with
+  constexpr int kWuMax = 1024;
+  int Wu = 128;
+  if (const char *wus = std::getenv("TEHMM_LANE_WARMUP")) Wu = std::min(kWuMax, std::max(1, std::atoi(wus)));
+  else if (w.wu_ok > 0 && w.wu_model == m->uid) Wu = w.wu_ok;
+  int attempts = 0;
+  for (;;) {
+    if (int rc = wide_post_attempt(b, m, iv, Wu, st, b->ev[8], true)) return rc;
+    w.pp_active = false;
+    ++attempts;
+    HIPCHK(hipStreamSynchronize(st));
+    if (std::getenv("TEHMM_SPEC_DEBUG"))
+      std::fprintf(stderr, "[tehmm wide estep] NPW %d L %d Wu %d: impossible rows in %d items, failed links %d of %d items\n", NPW,
+                   L, Wu, w.h_flags[0], w.h_flags[1], w.n_items);
+    if (w.h_flags[0] > 0) return TEHMM_OK;             // impossible rows: the sequential kernels own their semantics
+    if (w.h_flags[1] == 0) break;
+    if (Wu >= kWuMax) return TEHMM_OK;                 // does not forget: the caller falls back
+    Wu = std::min(kWuMax, 2 * Wu);
+    HIPCHK(hipMemsetAsync(w.flags.p, 0, 4 * sizeof(int), st));
+    (void)hipEventRecord(b->ev[9], st);
+  }
+  w.wu_ok = Wu;
+  w.wu_model = m->uid;
+  w.wu_version = m->version;
+  (void)hipEventRecord(b->ev[6], st);
+  hipLaunchKernelGGL(k_wide_loglik, dim3((b->n + 63) / 64), dim3(64), 0, st, iv, lg, m->N, NPW, (const double *)w.end_f.p,
+                     (const double *)w.SL.p, (const double *)w.lr.p, b->fwd_lp.p);
+  int rcr = TEHMM_OK;
+  switch (NPW) {
+    case 16: rcr = launch_wide_estep_reduce<16>(b, m, iv, lg, ratio, dev_stats, st); break;
+    case 32: rcr = launch_wide_estep_reduce<32>(b, m, iv, lg, ratio, dev_stats, st); break;
+    case 48: rcr = launch_wide_estep_reduce<48>(b, m, iv, lg, ratio, dev_stats, st); break;
+    case 64: rcr = launch_wide_estep_reduce<64>(b, m, iv, lg, ratio, dev_stats, st); break;
+    case 80: rcr = launch_wide_estep_reduce<80>(b, m, iv, lg, ratio, dev_stats, st); break;
+    case 96: rcr = launch_wide_estep_reduce<96>(b, m, iv, lg, ratio, dev_stats, st); break;
+    case 112: rcr = launch_wide_estep_reduce<112>(b, m, iv, lg, ratio, dev_stats, st); break;
+    default: rcr = launch_wide_estep_reduce<128>(b, m, iv, lg, ratio, dev_stats, st); break;
+  }
+  if (rcr) return rcr;
+  (void)hipEventRecord(b->ev[7], st);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  // stage times of the LAST attempt (emission rows: first attempt only)
+  static const struct { const char *name; int a, b2; } stages[] = {
+      {"estep_emission_rows", 10, 9}, {"estep_forward_pass", 9, 8}, {"estep_backward_pass", 8, 6}, {"estep_reduce", 6, 7}};
+  for (const auto &sg : stages) {
+    float ms = 0.f;
+    if (attempts > 1 && sg.a == 10) continue;
+    (void)hipEventElapsedTime(&ms, b->ev[sg.a], b->ev[sg.b2]);
+    b->tnames.push_back(sg.name);
+    b->tms.push_back((double)ms);
+  }
+  b->tnames.push_back("count:wide_estep_attempts");
+  b->tms.push_back((double)attempts);
+  b->tnames.push_back("count:wide_estep_warmup");
+  b->tms.push_back((double)Wu);
+  std::vector<double> lp((size_t)b->n);
+  HIPCHK(hipMemcpy(lp.data(), b->fwd_lp.p, (size_t)b->n * sizeof(double), hipMemcpyDeviceToHost));
+  double lp_total = 0.0;
+  for (int id = 0; id < b->n; ++id) {
+    if (b->h_len[(size_t)id] <= 0) continue;
+    lp_total += lp[(size_t)id];
+    b->h_fwd_lp[(size_t)id] = lp[(size_t)id];
+  }
+  *lp_out = lp_total;
+  *dead_out = 0;
+  *done = true;
+  return TEHMM_OK;
+}
+
 // Raw statistics of every interval of the batch ADDED into dev_stats (device buffer of
 // stats_size(NP, R) doubles, layout in tehmm_aux.hip.h); *dead_any: some interval met an impossible row
 // after its first emittable one (the reference's lattices are NaN there).
 static int estep_accumulate(tehmm_model_t *m, tehmm_batch_t *b, int use_ratios, double *dev_stats, double *lp_out,
                             int *dead_out) {
 #ifdef TEHMM_DEV_NT
-  if (m->NP != TEHMM_DEV_NT)
+  if (m->N < 64 && m->NP != TEHMM_DEV_NT)
     return fail(TEHMM_ERR_UNSUPPORTED, "development build: fused kernels exist for one padded state count only");
 #endif
   *lp_out = 0.0;
@@ -3691,11 +3946,21 @@ static int estep_accumulate(tehmm_model_t *m, tehmm_batch_t *b, int use_ratios, 
   if (b->n == 0 || b->total == 0) return TEHMM_OK;
   const bool ratio = use_ratios && b->has_ratios;
   const int N = m->N, NP = m->NP;
-  if (!ratio) {
+  {
     bool done = false;
-    int rcf = estep_fused(m, b, dev_stats, lp_out, dead_out, &done);
-    if (rcf) return rcf;
+    const char *wm = std::getenv("TEHMM_ESTEP_WIDE");
+    const bool wide_first = wm && std::atoi(wm) == 2;
+    if (!ratio && N < 64 && !wide_first) {
+      int rcf = estep_fused(m, b, dev_stats, lp_out, dead_out, &done);
+      if (rcf) return rcf;
+      if (done) return TEHMM_OK;
+    }
+    int rcw = estep_wide(m, b, ratio, dev_stats, lp_out, dead_out, &done);
+    if (rcw) return rcw;
     if (done) return TEHMM_OK;
+    if (N >= 64)
+      return fail(TEHMM_ERR_UNSUPPORTED, "E-step at N >= 64: the item-parallel passes do not apply to this batch (impossible "
+                                         "emission rows, links that do not verify, or a batch below 1024 rows): use the array-level path");
   }
   // Intervals are processed in groups whose alpha / beta / w rows fit a fixed workspace
   // (3 x 8N + 4 bytes per position, 40 % of the free HBM): the 3 Gb training sets of config 4
@@ -3791,7 +4056,7 @@ int tehmm_estep_batch_device(tehmm_model_t *m, tehmm_batch_t *b, int use_ratios,
   if (!m || !b || !dev_stats || !logprob_sum)
     return fail(TEHMM_ERR_ARG, "tehmm_estep_batch_device: NULL argument");
   if (m->K != b->K) return fail(TEHMM_ERR_ARG, "tehmm_estep_batch_device: model/batch track count differ");
-  if (m->N >= 64) return fail(TEHMM_ERR_UNSUPPORTED, "tehmm_estep_batch_device: N >= 64 (use the array-level path)");
+  if (m->N > 128) return fail(TEHMM_ERR_UNSUPPORTED, "tehmm_estep_batch_device: N > 128");
   double lp = 0.0;
   int dead = 0;
   int rc = estep_accumulate(m, b, use_ratios, dev_stats, &lp, &dead);
@@ -3818,7 +4083,7 @@ int tehmm_estep_batch(tehmm_model_t *m, tehmm_batch_t *b, int use_ratios, double
   if (!m || !b || !start || !trans || !obsStats || !logprob_sum)
     return fail(TEHMM_ERR_ARG, "tehmm_estep_batch: NULL argument");
   if (m->K != b->K) return fail(TEHMM_ERR_ARG, "tehmm_estep_batch: model/batch track count differ");
-  if (m->N >= 64) return fail(TEHMM_ERR_UNSUPPORTED, "tehmm_estep_batch: N >= 64 (use the array-level path)");
+  if (m->N > 128) return fail(TEHMM_ERR_UNSUPPORTED, "tehmm_estep_batch: N > 128");
   *logprob_sum = 0.0;
   if (b->n == 0 || b->total == 0) return TEHMM_OK;
   const int N = m->N, NP = m->NP, K = m->K, S = m->S;

@@ -207,10 +207,13 @@ void k_wide_fwd(IntervalTab iv, LaneGeom lg, int N, int NP, int Wu, const double
 // post [T][N].  pre = w at the item's last position + 1 as the warm-up left it, end = w at its first position.
 // Items that end an interval start exactly from beta_{T-1} = 1.
 // ------------------------------------------------------------------------------------------
-template <int NPW>
+// ESTEP (tehmm_wide_estep.hip.h): instead of the posterior row, the float rows gamma_t = alpha'_t beta_t / G_t and
+// wz_t = w_{t+1} scale_t / G_t (zero at an interval's last position: no transition leaves it) in the alpha' layout.
+template <int NPW, bool ESTEP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_wide_bwd(IntervalTab iv, LaneGeom lg, int N, int NP, int Wu, const double *__restrict__ A,
-                const double *__restrict__ E, const float *__restrict__ AL, double *post, double *pre, double *end) {
+                const double *__restrict__ E, const float *__restrict__ AL, double *post, double *pre, double *end,
+                float *GAM = nullptr, float *WZ = nullptr) {
   using G = WideGeom<NPW>;
   constexpr int KS = G::KS, RT = G::RT;
   extern __shared__ double wide_lds[];
@@ -264,10 +267,20 @@ void k_wide_bwd(IntervalTab iv, LaneGeom lg, int N, int NP, int Wu, const double
       for (int k = 0; k < KS; ++k) gt += (double)ar[(int64_t)k << 6] * acc[k >> 2][k & 3];
       gt = item_sum4(gt);
       const double inv = 1.0 / gt;
-      double *pr = post + (r0 + s) * (int64_t)N + kq;
+      if (ESTEP) {
+        const int64_t ix = wide_al_index<NPW>(tile, L, s, 0, lane);
+        const double wzs = scale * inv;
 #pragma unroll
-      for (int k = 0; k < KS; ++k)
-        if (kq + 4 * k < N) pr[4 * k] = (((double)ar[(int64_t)k << 6] * acc[k >> 2][k & 3]) * inv + eps) * inv_epsden;
+        for (int k = 0; k < KS; ++k) {
+          GAM[ix + ((int64_t)k << 6)] = (float)(((double)ar[(int64_t)k << 6] * acc[k >> 2][k & 3]) * inv);
+          WZ[ix + ((int64_t)k << 6)] = s == top ? 0.f : (float)(v[k] * wzs);
+        }
+      } else {
+        double *pr = post + (r0 + s) * (int64_t)N + kq;
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+          if (kq + 4 * k < N) pr[4 * k] = (((double)ar[(int64_t)k << 6] * acc[k >> 2][k & 3]) * inv + eps) * inv_epsden;
+      }
     }                                 // (the four lanes of an item take the branch together: item_sum4 is safe)
     if (act) {
 #pragma unroll

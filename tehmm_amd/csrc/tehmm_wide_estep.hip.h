@@ -1,0 +1,289 @@
+// tehmm_wide_estep.hip.h -- the Baum-Welch E-step on the item-parallel passes of tehmm_wide.hip.h (round 4).
+//
+// Reference: BaseHMM.fit's per-sequence loop (basehmm.py:504-523) + MultitrackHmm._accumulate_sufficient_statistics
+// (hmm.py:545-574) + _hmm._log_sum_lneta (_hmm.pyx:62-117) + _emission.fastAccumulateStats (_emission.pyx:146-190),
+// for the two cases the fused passes of tehmm_estep.hip.h do not serve:
+//   * 64 <= N <= 128 states (BASELINE configs[4]: the 100-state model has to be TRAINED before it is evaluated);
+//     rounds 2-3 ran BaseHMM._do_estep over the array-level entry points, [T][N] fp64 lattices across PCIe five
+//     times per sequence;
+//   * segment ratios at any N <= 128 (fit on a segmented table, basehmm.py:510-512).  The passes of tehmm_wide.hip.h
+//     read their emission rows from HBM as exp(x - max), so the ratio is two more terms of x before the exponential:
+//         x_t[j] = r_t * normalize * sum_k logb_k[j]  +  [r_t > 1] lt[j][j] (r_t - 1)      (_hmm.pyx:131-140, 178-181)
+//     and the recurrences themselves do not change.  Rounds 2-3: ONE sequential chain per interval (k_fb_coop<TRATIO>).
+//
+// k_wide_fwd leaves alpha'_t as floats; k_wide_bwd<ESTEP> leaves, in the same layout,
+//     gamma_t = alpha'_t beta_t / G_t                 -> start, emission histograms, the diagonal ratio term
+//     wz_t    = w_{t+1} scale_t / G_t                 -> xi_t(i, j) = alpha'_t[i] A[i][j] wz_t[j]
+// The layout (wide_al_index) is, per (16-item tile, position s), a dense [state][item] float matrix: element
+// (state j, item i) at ((tile L + s) NPW + j) 16 + i.  Both reductions are GEMMs contracted over the items, on the fp64
+// matrix cores (v_mfma_f64_16x16x4: products of floats are exact in fp64, the sums are fp64):
+//   * k_wide_estep_xi:    C[i][j] += sum_{items, s} alpha'[i][item] wz[j][item]
+//   * k_wide_estep_rows:  out[row][j] += sum_{items, s} a[row][item] gamma[j][item], where a row is
+//         (track, symbol):  a = r_t [obs_t[track] == symbol]          (fastAccumulateStats: posterior * segRatio)
+//         START:            a = [t == 0]                              (stats['start'] += posteriors[0])
+//         DIAG:             a = [t > 0 and r_t > 1] (r_t - 1)         (the `y` term of _log_sum_lneta, _hmm.pyx:94-99:
+//                                                                      exp(fwd + bwd + log(r - 1) - logprob) = gamma (r - 1))
+//     so every statistic that is linear in gamma comes out of ONE product.
+// An operand lane holds FOUR CONSECUTIVE ITEMS of its row (one 16-byte load): the contraction index k of the four
+// matrix instructions of a step is item 4 (lane >> 4) + kk -- any bijection items <-> (lane >> 4, kk) is legal as
+// long as both operands use it.
+// Slots no pass ever writes (positions beyond an item's end, items beyond the last) are zero from the allocation on,
+// so the reductions need no masks.  Sums are reproducible: every writer owns a slot of a partial buffer, the fold
+// kernels add the slots in ascending order (as tehmm_estep.hip.h).
+// There is no exact chain here: an attempt whose links do not verify is repeated with twice the warm-up, then the
+// caller falls back (sequential kernels below 64 states, TEHMM_ERR_UNSUPPORTED -> array-level host loop above).
+// Tolerance: rows are floats, sums fp64: statistics to ~1e-7 of the reference (bar 1e-6, tests/test_gpu_r4.py).
+#pragma once
+#include "tehmm_wide.hip.h"
+#include "tehmm_estep.hip.h"
+
+#define TEHMM_WIDE_ROW_START 0x40000000
+#define TEHMM_WIDE_ROW_DIAG 0x40000001
+
+namespace tehmm {
+
+struct WideRows {
+  int n_rt;                              // row tiles (16 rows each)
+  int info[TEHMM_ESTEP_MAXRT * 16];      // row -> observation column | symbol << 8, a TEHMM_WIDE_ROW_* code, or -1 (padding)
+  int grow[TEHMM_ESTEP_MAXRT * 16];      // (track, symbol) row -> row of the global statistics table
+};
+
+// ---- emission rows for fit: E [row][NPW] = exp(x - max), ms [row] = max, with the segment ratios applied the way
+// fit applies them (the emission ratio comes through em.ratios, the transition term is added here) -----------------
+template <bool TRATIO>
+__global__ __launch_bounds__(256) void k_wide_emis_fit(IntervalTab iv, EmisTab em, LaneGeom lg, int N, int NPW, int NP,
+                                                       const double *__restrict__ g_lt, const double *__restrict__ tratios,
+                                                       double *E, double *ms, int *flags) {
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= lg.n_items) return;
+  const int id = lg.item_iv[item];
+  const int64_t t0 = lg.item_t0[item], T = iv.len[id], p0 = iv.pos0[id], r0 = iv.out0[id];
+  const int len = (int)min((int64_t)lg.L, T - t0);
+  const double ltd0 = lane < N ? g_lt[(size_t)lane * NP + lane] : 0.0;
+  const double ltd1 = lane + 64 < N ? g_lt[(size_t)(lane + 64) * NP + lane + 64] : 0.0;
+  bool bad = false;
+  for (int s = 0; s < len; ++s) {
+    double x[2];
+    emis_log_wide(em, em.tab, p0 + t0 + s, lane, N, x);
+    if (TRATIO) {
+      const double r = tratios[p0 + t0 + s];
+      if (r > 1.) { x[0] += ltd0 * (r - 1.); x[1] += ltd1 * (r - 1.); }
+    }
+    const double m = row_max<2>(x, lane, N);
+    const bool good = m > -1e20;
+    bad = bad | !good;
+    double *dst = E + (r0 + t0 + s) * (int64_t)NPW;
+    if (lane < NPW) dst[lane] = (good && lane < N) ? exp_nonpos(x[0] - m) : 0.0;
+    if (lane + 64 < NPW) dst[lane + 64] = (good && lane + 64 < N) ? exp_nonpos(x[1] - m) : 0.0;
+    if (lane == 0) ms[r0 + t0 + s] = good ? m : 0.0;
+  }
+  if (bad && lane == 0) atomicAdd(&flags[0], 1);
+}
+
+template <int NPW>
+struct WideEstepGeom {
+  static constexpr int RT = NPW / 16;                        // state tiles
+  static constexpr int RSPLIT = RT > 4 ? 4 : 1;              // waves of a workgroup that share one item tile (xi)
+  static constexpr int RPW = (RT + RSPLIT - 1) / RSPLIT;     // row tiles of the xi product per wave
+  static constexpr int TPW = 4 / RSPLIT;                     // item tiles a workgroup works on at a time
+};
+
+// longest item of a 16-item tile (wave-uniform)
+__device__ __forceinline__ int wide_tile_nsmax(const IntervalTab &iv, const LaneGeom &lg, int64_t tile, int lane) {
+  const int64_t item = tile * 16 + (lane & 15);
+  const bool valid = item < lg.n_items;
+  const int id = valid ? lg.item_iv[item] : 0;
+  const int64_t t0 = valid ? lg.item_t0[item] : 0;
+  int ns = valid ? (int)min((int64_t)lg.L, iv.len[id] - t0) : 0;
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) ns = max(ns, __shfl_xor(ns, o));
+  return __builtin_amdgcn_readfirstlane(ns);
+}
+
+// ------------------------------------------------------------------------------------------
+// xi:  C[i][j] += sum over (item, position) alpha'[i] wz[j].  grid = persistent workgroups, block = 256.
+// NPW > 64: the four waves share an item tile and split the row tiles of C (wave w: row tiles w, w + 4);
+// NPW <= 64: every wave takes its own item tile and the whole of C.
+// part: [gridDim.x * TPW slots][NPW][NPW]; every cell of every slot is written.
+// ------------------------------------------------------------------------------------------
+template <int NPW>
+__global__ __launch_bounds__(256) void k_wide_estep_xi(IntervalTab iv, LaneGeom lg, const float *__restrict__ AL,
+                                                       const float *__restrict__ WZ, double *part) {
+  using G = WideEstepGeom<NPW>;
+  constexpr int RT = G::RT, RSPLIT = G::RSPLIT, RPW = G::RPW, TPW = G::TPW;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int sub = wv % RSPLIT, tsel = wv / RSPLIT;
+  const int m = lane & 15, k4 = lane >> 4;
+  lane_d4 acc[RPW][RT];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int tb = 0; tb < RT; ++tb) acc[r][tb] = (lane_d4){0.0, 0.0, 0.0, 0.0};
+  const int64_t n_tiles = ((int64_t)lg.n_items + 15) / 16;
+  const float4 *al4 = (const float4 *)AL, *wz4 = (const float4 *)WZ;
+  for (int64_t tile = (int64_t)blockIdx.x * TPW + tsel; tile < n_tiles; tile += (int64_t)gridDim.x * TPW) {
+    const int nsmax = wide_tile_nsmax(iv, lg, tile, lane);
+    if (nsmax <= 0) continue;
+    // float4 (tile, s, state, k4) = ((tile L + s) NPW + state) 4 + k4
+    const int64_t b4 = tile * lg.L * (int64_t)(NPW * 4) + m * 4 + k4;
+    float4 xa[RPW], xw[RT];
+    auto request = [&](int s) {
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        const int ta = min(sub + RSPLIT * r, RT - 1);
+        xa[r] = al4[b4 + ((int64_t)s * NPW + 16 * ta) * 4];
+      }
+#pragma unroll
+      for (int tb = 0; tb < RT; ++tb) xw[tb] = wz4[b4 + ((int64_t)s * NPW + 16 * tb) * 4];
+    };
+    request(0);
+    for (int s = 0; s < nsmax; ++s) {
+      double a[RPW][4], w[RT][4];
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        a[r][0] = (double)xa[r].x; a[r][1] = (double)xa[r].y; a[r][2] = (double)xa[r].z; a[r][3] = (double)xa[r].w;
+      }
+#pragma unroll
+      for (int tb = 0; tb < RT; ++tb) {
+        w[tb][0] = (double)xw[tb].x; w[tb][1] = (double)xw[tb].y; w[tb][2] = (double)xw[tb].z; w[tb][3] = (double)xw[tb].w;
+      }
+      if (s + 1 < nsmax) request(s + 1);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+          if (sub + RSPLIT * r < RT) {
+#pragma unroll
+            for (int tb = 0; tb < RT; ++tb)
+              acc[r][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r][kk], w[tb][kk], acc[r][tb], 0, 0, 0);
+          }
+        }
+    }
+  }
+  // accumulator (lane, register q) of (row tile ta, column tile tb) is C[16 ta + 4 q + (lane >> 4)][16 tb + (lane & 15)]
+  double *slot = part + ((size_t)blockIdx.x * TPW + tsel) * (size_t)(NPW * NPW);
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int ta = sub + RSPLIT * r;
+    if (ta < RT) {
+#pragma unroll
+      for (int tb = 0; tb < RT; ++tb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) slot[(size_t)(16 * ta + 4 * q + k4) * NPW + 16 * tb + m] = acc[r][tb][q];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Everything linear in gamma: out[row][j] += sum over (item, position) a[row][item] gamma[j][item].
+// grid (x = persistent workgroups over the item tiles, y = groups of four row tiles), block = 256: wave w owns row
+// tile 4 y + w.  part: [gridDim.x slots][n_rt * 16 rows][NPW].
+// ------------------------------------------------------------------------------------------
+template <int NPW, bool RATIO>
+__global__ __launch_bounds__(256) void k_wide_estep_rows(IntervalTab iv, LaneGeom lg, const WideRows *__restrict__ wr, int KP,
+                                                         const uint8_t *__restrict__ obs, const double *__restrict__ ratios,
+                                                         const float *__restrict__ GAM, double *part) {
+  constexpr int RT = NPW / 16;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int m = lane & 15, k4 = lane >> 4;
+  const int nrt = wr->n_rt;
+  const int rt = blockIdx.y * 4 + wv;
+  if (rt >= nrt) return;                                   // (no barrier in this kernel)
+  const int inf = wr->info[rt * 16 + m];
+  const int kind = inf < 0 ? 3 : inf == TEHMM_WIDE_ROW_START ? 1 : inf == TEHMM_WIDE_ROW_DIAG ? 2 : 0;
+  const int col = kind == 0 ? (inf & 255) : 0, rsym = kind == 0 ? (inf >> 8) : -1;
+  lane_d4 acc[RT];
+#pragma unroll
+  for (int tb = 0; tb < RT; ++tb) acc[tb] = (lane_d4){0.0, 0.0, 0.0, 0.0};
+  const int64_t n_tiles = ((int64_t)lg.n_items + 15) / 16;
+  const float4 *gam4 = (const float4 *)GAM;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // the lane's four items 4 k4 + kk: observation rows, ratios, lengths
+    int64_t oo[4], rp[4], t0k[4];
+    int nsk[4], nsmax = 0;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int64_t item = tile * 16 + 4 * k4 + kk;
+      const bool valid = item < lg.n_items;
+      const int64_t itc = valid ? item : (int64_t)lg.n_items - 1;
+      const int id = lg.item_iv[itc];
+      const int64_t t0 = lg.item_t0[itc];
+      nsk[kk] = valid ? (int)min((int64_t)lg.L, iv.len[id] - t0) : 0;
+      rp[kk] = iv.pos0[id] + t0;
+      oo[kk] = rp[kk] * KP + col;
+      t0k[kk] = t0;
+      nsmax = max(nsmax, nsk[kk]);
+    }
+    nsmax = max(nsmax, __shfl_xor(nsmax, 16));
+    nsmax = max(nsmax, __shfl_xor(nsmax, 32));
+    nsmax = __builtin_amdgcn_readfirstlane(nsmax);
+    if (nsmax <= 0) continue;
+    const int64_t b4 = tile * lg.L * (int64_t)(NPW * 4) + m * 4 + k4;
+    float4 xg[RT];
+    int sy[4];
+    double rr[4];
+    auto request = [&](int s) {
+#pragma unroll
+      for (int tb = 0; tb < RT; ++tb) xg[tb] = gam4[b4 + ((int64_t)s * NPW + 16 * tb) * 4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int sc = max(0, min(s, nsk[kk] - 1));           // unconditional loads from inside the item
+        sy[kk] = (int)obs[oo[kk] + (int64_t)sc * KP];
+        rr[kk] = RATIO ? ratios[rp[kk] + sc] : 1.0;
+      }
+    };
+    request(0);
+    for (int s = 0; s < nsmax; ++s) {
+      double a[4], g[RT][4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const double r = rr[kk];
+        double v = (sy[kk] == rsym) ? r : 0.0;                                        // kind 0 (rsym = -1 otherwise)
+        v = kind == 1 ? ((s == 0 && t0k[kk] == 0) ? 1.0 : 0.0) : v;
+        v = kind == 2 ? ((RATIO && r > 1. && t0k[kk] + s > 0) ? r - 1. : 0.0) : v;
+        a[kk] = s < nsk[kk] ? v : 0.0;
+      }
+#pragma unroll
+      for (int tb = 0; tb < RT; ++tb) {
+        g[tb][0] = (double)xg[tb].x; g[tb][1] = (double)xg[tb].y; g[tb][2] = (double)xg[tb].z; g[tb][3] = (double)xg[tb].w;
+      }
+      if (s + 1 < nsmax) request(s + 1);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int tb = 0; tb < RT; ++tb) acc[tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], g[tb][kk], acc[tb], 0, 0, 0);
+    }
+  }
+  double *slot = part + (size_t)blockIdx.x * (size_t)(nrt * 16) * NPW;
+#pragma unroll
+  for (int tb = 0; tb < RT; ++tb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) slot[(size_t)(rt * 16 + 4 * q + k4) * NPW + 16 * tb + m] = acc[tb][q];
+}
+
+// ---- the ordered sums over the writers' slots (one thread per cell, slots ascending) ----------------------------
+__global__ __launch_bounds__(256) void k_wide_fold_xi(const double *__restrict__ part, int nslot, int N, int NPW, int NP, double *gC) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * N) return;
+  const int i = idx / N, j = idx - i * N;
+  double sum = 0.0;
+  for (int s = 0; s < nslot; ++s) sum += part[(size_t)s * NPW * NPW + (size_t)i * NPW + j];
+  gC[(size_t)i * NP + j] += sum;
+}
+__global__ __launch_bounds__(256) void k_wide_fold_rows(const double *__restrict__ part, int nslot, int N, int NPW, int NP,
+                                                        const WideRows *__restrict__ wr, double *gstat, double *gstart, double *gD) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nrow = wr->n_rt * 16;
+  if (idx >= nrow * N) return;
+  const int row = idx / N, j = idx - row * N;
+  const int inf = wr->info[row];
+  if (inf < 0) return;
+  double sum = 0.0;
+  for (int s = 0; s < nslot; ++s) sum += part[((size_t)s * nrow + row) * NPW + j];
+  if (inf == TEHMM_WIDE_ROW_START) gstart[j] += sum;
+  else if (inf == TEHMM_WIDE_ROW_DIAG) gD[j] += sum;
+  else gstat[(int64_t)wr->grow[row] * NP + j] += sum;
+}
+
+}  // namespace tehmm

@@ -324,8 +324,16 @@ class MultitrackHmm(BaseHMM):
     def _do_estep(self, obs, stats):
         """E-step over all sequences.  When every sequence is a uint8 table the fused device entry
         point (tehmm_estep_batch) does the whole loop of basehmm.py:507-522 in one call."""
-        if self._can_fuse(obs) and self.n_components < 64:
-            return self._fused_estep(obs, stats)
+        if self._can_fuse(obs) and self.n_components <= 128:
+            from ._lib import TeHmmHipError
+            try:
+                return self._fused_estep(obs, stats)
+            except TeHmmHipError as e:
+                # 64..128 states run on the item-parallel passes only (tehmm_wide_estep.hip.h): a batch they do not
+                # apply to (impossible emission rows, links that never verify, fewer than 1024 rows) takes the
+                # reference's per-sequence loop over the array-level entry points
+                if e.code != -3 or self.n_components < 64:
+                    raise
         return BaseHMM._do_estep(self, obs, stats)
 
     def _fused_estep(self, tables, stats):
@@ -415,7 +423,9 @@ class MultitrackHmm(BaseHMM):
             return False
         # (decided on the GLOBAL table list, which every rank passes alike: no rank may leave the others alone
         #  in the per-iteration all-reduce)
-        return em.zeroAsMissingData is True and self.n_components < 64 and len(obs) > 0 and self._can_fuse(obs)
+        if self.n_components >= 64 and sum(len(t) for t in obs if t is not None) < 1024:
+            return False                               # (the item-parallel passes want 1024 rows)
+        return em.zeroAsMissingData is True and self.n_components <= 128 and len(obs) > 0 and self._can_fuse(obs)
 
     def _fit_device(self, tables, lengths=None):
         """BaseHMM.fit (basehmm.py:475-541) with the observations, the sufficient statistics and the

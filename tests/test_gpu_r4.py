@@ -246,3 +246,153 @@ def test_eval_stream_matches_one_batch(monkeypatch):
         assert_array_equal(ps[i], paths[sl])
         assert_allclose(qs[i], post[sl], rtol=1e-6, atol=1e-15)
         assert_allclose(ms[i], post[sl] @ mask, rtol=1e-6, atol=1e-15)
+
+
+# ------------------------------------------------------------------ E-step on the item-parallel passes (64..128 states, ratios)
+def _rel(a, b, floor=1e-9):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    m = np.abs(b) > floor
+    return float(np.max(np.abs(a - b)[m] / np.abs(b)[m])) if m.any() else 0.0
+
+
+def _seg_ratios(total, seed, mean=4.0):
+    """Segment-length ratios as emission.getSegmentRatios gives them: length / mean length, many of them 1."""
+    rs = np.random.RandomState(seed)
+    r = np.clip(rs.geometric(1.0 / mean, size=total), 1, 60).astype(np.float64) / mean
+    r[rs.rand(total) < 0.3] = 1.0
+    return r
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("N,symbols,gauss,use_ratios", [
+    (100, (3, 5, 4, 30), (), False),                      # BASELINE configs[4] model
+    (100, (3, 5, 4, 30), (), True),                       # ... trained on a segmented table
+    (128, (2, 7), (), True),                              # the largest model, no pad states
+    (64, (3, 5, 4, 30), (), False),                       # the smallest one the fused passes do not take
+    (35, (3, 5, 4, 30, 250), (4,), True),                 # segment ratios below 64 states: 48 padded states here
+    (5, (3, 5, 4), (), True),                             # one state tile
+    (60, (4, 250, 30), (1,), True),                       # 64 padded states, a 250-bin track in the gamma product
+])
+def test_wide_estep_vs_oracle(monkeypatch, N, symbols, gauss, use_ratios):
+    """tehmm_estep_batch on the item-parallel passes (k_wide_emis_fit, k_wide_fwd, k_wide_bwd<ESTEP>, k_wide_estep_xi,
+    k_wide_estep_rows) against the oracle's per-sequence E-step (basehmm.py:504-523, hmm.py:545-574,
+    _hmm.pyx:62-117 with the diagonal ratio term, _emission.pyx:183-190 with ratio-weighted posteriors) on ragged
+    intervals: one-row, sub-item and multi-item intervals, tails shorter than an item.  Statistics at 1e-6 (written
+    here); the observed error is asserted at 3e-7 so that a loss of margin shows; same input, same bits."""
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    from oracle import oracle
+    for k in KNOBS + ("TEHMM_ESTEP_WIDE", "TEHMM_WIDE_SUB", "TEHMM_LANE_WARMUP"):
+        monkeypatch.delenv(k, raising=False)
+    model = synth.make_model(N, symbols, gauss, seed=12 + N)
+    rs = np.random.RandomState(3 + N)
+    lens = [int(x) for x in rs.randint(3000, 9000, size=4)] + [1, 70, 1500, 1024, 2048 + 64]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    total = int(offs[-1])
+    obs = synth.sample_obs(model, total, seed=5, missing=0.02)
+    r = _seg_ratios(total, 7) if use_ratios else None
+    K, _, S = model.log_probs.shape
+    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, 1.0, model.symbols_per_track)
+    got = []
+    for rep in range(2):
+        hb = HipBatch(obs, offs, r)
+        start, trans, st = np.zeros(N), np.zeros((N, N)), np.zeros((K, N, S))
+        lp = hm.estep(hb, use_ratios, start, trans, st)
+        tm = hb.timing()
+        got.append((lp, start, trans, st, hb.interval_logprobs()))
+        hb.close()
+        assert "estep_emission_rows" in tm and tm["count:wide_estep_attempts"] >= 1       # the path under test ran
+    ref = oracle.estep([obs[offs[i]:offs[i + 1]] for i in range(len(lens))], model.log_probs, model.log_startprob,
+                       model.log_transmat, 1.0, [r[offs[i]:offs[i + 1]] for i in range(len(lens))] if use_ratios else None)
+    lp, start, trans, st, ilp = got[0]
+    assert_allclose(lp, ref["logprob"], rtol=1e-9)
+    assert_allclose(ilp.sum(), ref["logprob"], rtol=1e-9)
+    assert_allclose(start, ref["start"], rtol=1e-6, atol=1e-12)
+    assert_allclose(trans, ref["trans"], rtol=1e-6, atol=1e-9)
+    assert_allclose(st, ref["obs"], rtol=1e-6, atol=1e-9)
+    worst = max(_rel(start, ref["start"]), _rel(trans, ref["trans"], 1e-6), _rel(st, ref["obs"], 1e-6))
+    print("wide E-step N=%d ratios=%s: max rel error of the statistics %.3g" % (N, use_ratios, worst))
+    assert worst <= 3e-7
+    for a, b in zip(got[0], got[1]):                                   # reproducible sums (ordered folds)
+        assert_array_equal(np.asarray(a), np.asarray(b))
+    if N < 64:
+        # the sequential kernels (k_fb_coop<TRATIO> + k_estep_accum) on the same batch
+        monkeypatch.setenv("TEHMM_ESTEP_WIDE", "0")
+        hb = HipBatch(obs, offs, r)
+        s2, t2, st2 = np.zeros(N), np.zeros((N, N)), np.zeros((K, N, S))
+        lp2 = hm.estep(hb, use_ratios, s2, t2, st2)
+        assert "estep_emission_rows" not in hb.timing()
+        hb.close()
+        assert_allclose(lp2, lp, rtol=1e-9)
+        assert_allclose(t2, trans, rtol=1e-6, atol=1e-9)
+        assert_allclose(st2, st, rtol=1e-6, atol=1e-9)
+    hm.close()
+
+
+def test_wide_estep_falls_back(monkeypatch):
+    """What the item-parallel passes do not take: a row no state can emit (the sequential kernels own the NaN semantics
+    below 64 states; TEHMM_ERR_UNSUPPORTED at 64 and above, where MultitrackHmm._do_estep then runs the reference's
+    per-sequence loop over the array-level entry points)."""
+    from tehmm_amd import _lib, synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    for k in KNOBS + ("TEHMM_ESTEP_WIDE",):
+        monkeypatch.delenv(k, raising=False)
+    for N in (6, 70):
+        model = synth.make_model(N, (3, 5, 4), (), seed=21)
+        lp3 = model.log_probs.copy()
+        lp3[1, :, 2] = -np.inf                      # symbol 2 of track 1 cannot be emitted by any state
+        lens = [5000, 3000]
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        obs = synth.sample_obs(model, int(offs[-1]), seed=2)
+        obs[:, 1] = np.where(obs[:, 1] == 2, 1, obs[:, 1])
+        obs[6000, 1] = 2
+        r = _seg_ratios(int(offs[-1]), 3)
+        hm = HipModel(model.log_transmat, model.log_startprob, lp3, 1.0, model.symbols_per_track)
+        hb = HipBatch(obs, offs, r)
+        K, _, S = lp3.shape
+        start, trans, st = np.zeros(N), np.zeros((N, N)), np.zeros((K, N, S))
+        if N >= 64:
+            with pytest.raises(_lib.TeHmmHipError) as ei:
+                hm.estep(hb, True, start, trans, st)
+            assert ei.value.code == -3
+        else:
+            lp = hm.estep(hb, True, start, trans, st)
+            assert np.isnan(lp) and np.isnan(trans).all()           # the reference's NaN lattices (sequential path)
+        hb.close()
+        hm.close()
+
+
+@pytest.mark.timeout(900)
+def test_device_em_100_states_matches_host_loop(monkeypatch):
+    """MultitrackHmm.fit at 100 states: device-resident EM (_fit_device over tehmm_estep_batch_device on the
+    item-parallel passes + tehmm_model_mstep) against BaseHMM.fit's per-sequence loop over the array-level entry
+    points (TEHMM_DEVICE_EM=0, TEHMM_ESTEP_WIDE=0: what rounds 1-3 ran at this size), two iterations."""
+    from tehmm_amd import synth
+    from tehmm_amd.emission import IndependentMultinomialEmissionModel
+    from tehmm_amd.hmm import MultitrackHmm
+    for k in KNOBS + ("TEHMM_ESTEP_WIDE", "TEHMM_DEVICE_EM"):
+        monkeypatch.delenv(k, raising=False)
+    N, sym = 100, [3, 5, 4, 30]
+    truth = synth.make_model(N, tuple(sym), (), seed=3)
+    init = synth.make_model(N, tuple(sym), (), seed=4)
+    seqs = [synth.sample_obs(truth, T, seed=50 + i, missing=0.02) for i, T in enumerate([2500, 1800, 700])]
+
+    def fresh():
+        em = IndependentMultinomialEmissionModel(N, sym)
+        em.logProbs = init.log_probs.copy()
+        h = MultitrackHmm(em, n_iter=2, thresh=0.0, fixStart=False)
+        h.transmat_ = init.transmat.copy()
+        h.init_params = ""
+        return h
+
+    a = fresh()
+    assert a._can_fit_on_device(seqs)
+    a.fit(seqs)
+    monkeypatch.setenv("TEHMM_DEVICE_EM", "0")
+    monkeypatch.setenv("TEHMM_ESTEP_WIDE", "0")
+    b = fresh()
+    assert not b._can_fit_on_device(seqs)
+    b.fit(seqs)
+    assert_allclose(a._log_transmat, b._log_transmat, rtol=1e-6, atol=1e-9)
+    assert_allclose(a.emissionModel.logProbs, b.emissionModel.logProbs, rtol=1e-6, atol=1e-9)
+    assert_allclose(a._log_startprob, b._log_startprob, rtol=1e-6, atol=1e-9)
