@@ -385,8 +385,14 @@ struct WideWork {
   bool al_zeroed = false;
   WideRows h_rows;
   DBuf<WideRows> d_rows;
+  WideLds h_lds;
+  DBuf<WideLds> d_lds;
+  int lds_nsplit = 1;
   uint64_t rows_model = 0;
-  DBuf<double> part_xi, part_rows;
+  int rows_npw = 0;
+  DBuf<double> part_xi, part_rows, part_lds;
+  DBuf<unsigned long long> d_rmax;
+  double ratio_max = 0.0;          // largest segment ratio of the batch (0: not yet known)
   // chunk-parallel exact Viterbi (k_vit_wide_spec / k_vit_wide_fix)
   DBuf<double> BL;                 // log emission rows [internal position][128]
   DBuf<double> rows2;              // recorded rows of the second tie hypothesis
@@ -1970,9 +1976,17 @@ static int wide_post_attempt(tehmm_batch *b, const tehmm_model *m, const Interva
     case 112: launch_wide_passes<112>(b, m, iv, lg, Wu, st, mid); break;
     default: launch_wide_passes<128>(b, m, iv, lg, Wu, st, mid); break;
   }
+  // link tolerance (Hilbert distance between the vector an item arrives with and the one its neighbour left): 1e-10 for
+  // posteriors that are handed out as doubles; 1e-8 for the E-step, whose rows are floats (6e-8 each) and whose error at
+  // an item's first position is the link's distance, smaller further in -- half the warm-up at 100 states
+  double tol = TEHMM_FB_TOL;
+  if (estep) {
+    tol = 1e-8;
+    if (const char *ts = std::getenv("TEHMM_WIDE_ESTEP_TOL")) tol = std::min(1e-6, std::max(1e-13, std::atof(ts)));
+  }
   hipLaunchKernelGGL(k_wide_links, dim3((w.n_items + 255) / 256), dim3(256), 0, st, iv, lg, m->N, NPW,
                      (const double *)w.pre_f.p, (const double *)w.end_f.p, (const double *)w.pre_b.p,
-                     (const double *)w.end_b.p, w.lr.p, w.flags.p);
+                     (const double *)w.end_b.p, w.lr.p, w.flags.p, tol);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(w.h_flags, w.flags.p, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
   w.pp_Wu = Wu;
@@ -2009,7 +2023,7 @@ static int posterior_wide_finish(tehmm_batch *b, const tehmm_model *m, const Int
   LaneGeom lg;
   lg.item_iv = w.item_iv.p; lg.item_t0 = w.item_t0.p; lg.ifirst = w.ifirst.p;
   lg.n_items = w.n_items; lg.n_groups = w.n_groups; lg.L = w.L;
-  hipLaunchKernelGGL(k_wide_loglik, dim3((b->n + 63) / 64), dim3(64), 0, st, iv, lg, m->N, w.NPW, (const double *)w.end_f.p,
+  hipLaunchKernelGGL(k_wide_loglik, dim3((b->n + 3) / 4), dim3(256), 0, st, iv, lg, m->N, w.NPW, (const double *)w.end_f.p,
                      (const double *)w.SL.p, (const double *)w.lr.p, b->fwd_lp.p);
   *done = true;
   return TEHMM_OK;
@@ -3746,7 +3760,7 @@ static bool estep_wide_wanted(const tehmm_model *m, const tehmm_batch *b, bool r
   if (const char *s = std::getenv("TEHMM_ESTEP_WIDE")) mode = std::atoi(s);
   if (mode == 0 || m->N > 128 || b->total < 1024) return false;
   if (mode == 1 && !(ratio || m->N >= 64)) return false;
-  if (m->R + 2 > TEHMM_ESTEP_MAXRT * 16 || m->K > 255) return false;
+  if (m->K > 255) return false;
   return true;
 }
 
@@ -3758,31 +3772,74 @@ static int launch_wide_estep_reduce(tehmm_batch *b, const tehmm_model *m, const 
   const int64_t n_tiles = ((int64_t)w.n_items + 15) / 16;
   double *gC = dev_stats + stats_off_C(m->NP), *gD = dev_stats + stats_off_D(m->NP), *gstart = dev_stats + stats_off_start(),
          *gstat = dev_stats + stats_off_stat(m->NP);
-  // xi: two workgroups per CU at most; gamma product: one item tile per workgroup at a time
-  const int gxm = (int)std::max<int64_t>(1, std::min<int64_t>((n_tiles + G::TPW - 1) / G::TPW, 512));
+  // work units = item tiles x SQ position ranges: at least ~4096 of them (a 2 Mb batch has 1000 item tiles; the GPU
+  // 1024 SIMDs), ranges of 16 positions or more
+  int SQ = 1;
+  while (SQ < 8 && n_tiles * SQ < 4096 && w.L / (2 * SQ) >= 16 && w.L % (2 * SQ) == 0) SQ *= 2;
+  if (const char *sq = std::getenv("TEHMM_WIDE_ESTEP_SQ")) {
+    const int v = std::atoi(sq);
+    if (v >= 1 && w.L % v == 0) SQ = v;
+  }
+  const int64_t n_units = n_tiles * SQ;
+  // xi: two workgroups per CU at most; gamma product: one unit per workgroup at a time, partial buffer <= 128 MB
+  const int gxm = (int)std::max<int64_t>(1, std::min<int64_t>((n_units + G::TPW - 1) / G::TPW, 512));
   HIPCHK(w.part_xi.ensure((size_t)gxm * G::TPW * NPW * NPW));
   const int nrt = w.h_rows.n_rt;
-  const int gxr = (int)std::max<int64_t>(1, std::min<int64_t>(n_tiles, 512));
+  const int64_t slot_rows = (int64_t)nrt * 16 * NPW * 8;
+  const int gxr = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_units, 1024), std::max<int64_t>(256, ((int64_t)128 << 20) / slot_rows)));
   HIPCHK(w.part_rows.ensure((size_t)gxr * nrt * 16 * NPW));
-  // the two products are independent: the gamma product runs on its own stream next to the xi product
+  // the products are independent: the gamma product and the LDS histograms run on their own streams next to the xi
+  // product (TEHMM_WIDE_ESTEP_SERIAL=1: one after the other, for profiling)
+  const bool serial = std::getenv("TEHMM_WIDE_ESTEP_SERIAL") != nullptr;
+  hipStream_t sB = serial ? st : b->sB, sV = serial ? st : b->sV;
   (void)hipEventRecord(b->evX[0], st);
-  (void)hipStreamWaitEvent(b->sB, b->evX[0], 0);
+  (void)hipStreamWaitEvent(sB, b->evX[0], 0);
   if (ratio)
-    hipLaunchKernelGGL((k_wide_estep_rows<NPW, true>), dim3(gxr, (nrt + 3) / 4), dim3(256), 0, b->sB, iv, lg,
+    hipLaunchKernelGGL((k_wide_estep_rows<NPW, true>), dim3(gxr, (nrt + 3) / 4), dim3(256), 0, sB, iv, lg,
                        (const WideRows *)w.d_rows.p, b->KP, (const uint8_t *)b->obs.p, (const double *)b->ratios.p,
-                       (const float *)w.GAM.p, w.part_rows.p);
+                       (const float *)w.GAM.p, w.part_rows.p, SQ);
   else
-    hipLaunchKernelGGL((k_wide_estep_rows<NPW, false>), dim3(gxr, (nrt + 3) / 4), dim3(256), 0, b->sB, iv, lg,
+    hipLaunchKernelGGL((k_wide_estep_rows<NPW, false>), dim3(gxr, (nrt + 3) / 4), dim3(256), 0, sB, iv, lg,
                        (const WideRows *)w.d_rows.p, b->KP, (const uint8_t *)b->obs.p, (const double *)nullptr,
-                       (const float *)w.GAM.p, w.part_rows.p);
-  hipLaunchKernelGGL(k_wide_fold_rows, dim3((nrt * 16 * m->N + 255) / 256), dim3(256), 0, b->sB, (const double *)w.part_rows.p,
+                       (const float *)w.GAM.p, w.part_rows.p, SQ);
+  hipLaunchKernelGGL(k_wide_fold_rows, dim3((nrt * 16 * m->N + 255) / 256), dim3(256), 0, sB, (const double *)w.part_rows.p,
                      gxr, m->N, NPW, m->NP, (const WideRows *)w.d_rows.p, gstat, gstart, gD);
-  (void)hipEventRecord(b->evX[1], b->sB);
+  (void)hipEventRecord(b->evX[1], sB);
+  if (w.h_lds.n_trk > 0) {
+    // tracks with many symbols: fixed-point histograms privatised in LDS, on a third stream
+    const int nsplit = w.lds_nsplit, HS = NPW / nsplit;
+    int max_rows = 0, tot_rows = 0;
+    for (int t = 0; t < w.h_lds.n_trk; ++t) { max_rows = std::max(max_rows, w.h_lds.rows[t]); tot_rows += w.h_lds.rows[t]; }
+    const size_t lds = (size_t)max_rows * HS * sizeof(unsigned long long);
+    const int gxl = (int)std::max<int64_t>(1, std::min<int64_t>((n_units + 7) / 8, 256));
+    HIPCHK(w.part_lds.ensure((size_t)gxl * tot_rows * NPW));
+    // the largest sum one workgroup can reach in a cell: its units x 16 items x L / SQ positions x the largest ratio
+    const int64_t per_wg = ((n_units + (int64_t)gxl * 8 - 1) / ((int64_t)gxl * 8)) * 8 * 16 * (int64_t)(w.L / SQ);
+    const double vmax = (double)per_wg * (ratio ? std::max(1.0, w.ratio_max) : 1.0);
+    int shift = 62;
+    while (shift > 20 && vmax * std::ldexp(1.0, shift) >= 9.2e18) --shift;
+    (void)hipStreamWaitEvent(sV, b->evX[0], 0);
+    const dim3 gl(gxl, w.h_lds.n_trk * nsplit);
+#define LDSK(NS_, R_)                                                                                                  \
+    do {                                                                                                               \
+      allow_lds(k_wide_estep_hist_lds<NPW, NS_, R_>, lds);                                                             \
+      hipLaunchKernelGGL((k_wide_estep_hist_lds<NPW, NS_, R_>), gl, dim3(512), lds, sV, iv, lg,                     \
+                         (const WideLds *)w.d_lds.p, m->N, b->KP, (const uint8_t *)b->obs.p,                           \
+                         (const double *)(R_ ? b->ratios.p : nullptr), (const float *)w.GAM.p, w.part_lds.p, shift, SQ); \
+    } while (0)
+    if (nsplit == 1) { if (ratio) LDSK(1, true); else LDSK(1, false); }
+    else { if (ratio) LDSK(2, true); else LDSK(2, false); }
+#undef LDSK
+    hipLaunchKernelGGL(k_wide_fold_lds, dim3((max_rows * HS + 255) / 256, w.h_lds.n_trk * nsplit), dim3(256), 0, sV,
+                       (const double *)w.part_lds.p, gxl, m->N, m->NP, HS, nsplit, (const WideLds *)w.d_lds.p, gstat);
+    (void)hipEventRecord(b->ev[11], sV);
+  }
   hipLaunchKernelGGL((k_wide_estep_xi<NPW>), dim3(gxm), dim3(256), 0, st, iv, lg, (const float *)w.AL.p, (const float *)w.WZ.p,
-                     w.part_xi.p);
+                     w.part_xi.p, SQ);
   hipLaunchKernelGGL(k_wide_fold_xi, dim3((m->N * m->N + 255) / 256), dim3(256), 0, st, (const double *)w.part_xi.p, gxm * G::TPW,
                      m->N, NPW, m->NP, gC);
   (void)hipStreamWaitEvent(st, b->evX[1], 0);
+  if (w.h_lds.n_trk > 0) (void)hipStreamWaitEvent(st, b->ev[11], 0);
   return TEHMM_OK;
 }
 
@@ -3825,20 +3882,56 @@ static int estep_wide(tehmm_model_t *m, tehmm_batch_t *b, bool ratio, double *de
     HIPCHK(b->dead.alloc((size_t)b->n + 1));
     if (!b->first_good.p) HIPCHK(b->first_good.alloc((size_t)b->n + 1));
   }
-  if (w.rows_model != m->uid || !w.d_rows.p) {
+  if (w.rows_model != m->uid || w.rows_npw != NPW || !w.d_rows.p) {
+    // tracks of more than TEHMM_ESTEP_SMALL rows whose histogram [rows][NPW or NPW / 2] fits a CU's LDS go there,
+    // the others (and START / DIAG) through the one-hot product
     WideRows &wr = w.h_rows;
+    WideLds &wl = w.h_lds;
+    std::memset(&wl, 0, sizeof(wl));
     for (int i = 0; i < TEHMM_ESTEP_MAXRT * 16; ++i) { wr.info[i] = -1; wr.grow[i] = 0; }
+    const int small = estep_small_threshold(m);
+    constexpr size_t kLdsCap = 150 * 1024;
+    int big_rows = 0;
+    for (int k = 0; k < m->K; ++k)
+      if (m->rowcnt[k] > small) big_rows = std::max(big_rows, m->rowcnt[k]);
+    w.lds_nsplit = (size_t)big_rows * NPW * 8 <= kLdsCap ? 1 : 2;
     int row = 0;
     wr.info[row++] = TEHMM_WIDE_ROW_START;
     wr.info[row++] = TEHMM_WIDE_ROW_DIAG;
-    for (int k = 0; k < m->K; ++k)
+    for (int k = 0; k < m->K; ++k) {
+      const bool to_lds = m->rowcnt[k] > small && (size_t)m->rowcnt[k] * (NPW / w.lds_nsplit) * 8 <= kLdsCap;
+      if (to_lds) {
+        wl.col[wl.n_trk] = k;
+        wl.rows[wl.n_trk] = m->rowcnt[k];
+        wl.gbase[wl.n_trk] = m->rowbase[k];
+        ++wl.n_trk;
+        continue;
+      }
       for (int sy = 0; sy < m->rowcnt[k]; ++sy, ++row) {
+        if (row >= TEHMM_ESTEP_MAXRT * 16) return TEHMM_OK;        // (more rows than the row table holds: fall back)
         wr.info[row] = (k & 255) | (sy << 8);
         wr.grow[row] = m->rowbase[k] + sy;
       }
+    }
     wr.n_rt = (row + 15) / 16;
     HIPCHK(w.d_rows.upload(&wr, 1));
+    HIPCHK(w.d_lds.upload(&wl, 1));
     w.rows_model = m->uid;
+    w.rows_npw = NPW;
+  }
+  if (ratio && w.h_lds.n_trk > 0 && w.ratio_max <= 0.0) {
+    // the fixed-point scale of the LDS histograms needs the largest ratio of the batch (once per batch)
+    if (!w.d_rmax.p) HIPCHK(w.d_rmax.alloc(1));
+    HIPCHK(hipMemset(w.d_rmax.p, 0, sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k_ratio_max, dim3(grid_for(b->total_pad, 256, 2048)), dim3(256), 0, b->sP, (const double *)b->ratios.p,
+                       b->total_pad, w.d_rmax.p);
+    unsigned long long bits = 0;
+    HIPCHK(hipMemcpyAsync(&bits, w.d_rmax.p, sizeof(bits), hipMemcpyDeviceToHost, b->sP));
+    HIPCHK(hipStreamSynchronize(b->sP));
+    double rmax = 0.0;
+    std::memcpy(&rmax, &bits, sizeof(rmax));
+    if (!(rmax < 1e12)) return TEHMM_OK;             // (inf / NaN ratios: the sequential kernels own their semantics)
+    w.ratio_max = std::max(rmax, 1e-300);
   }
   IntervalTab iv;
   EmisTab em;
@@ -3853,17 +3946,30 @@ static int estep_wide(tehmm_model_t *m, tehmm_batch_t *b, bool ratio, double *de
   b->tms.clear();
   (void)hipEventRecord(b->ev[10], st);
   HIPCHK(hipMemsetAsync(w.flags.p, 0, 4 * sizeof(int), st));
-  if (ratio)
-    hipLaunchKernelGGL((k_wide_emis_fit<true>), dim3((w.n_items + 3) / 4), dim3(256), 0, st, iv, emg, lg, m->N, NPW, m->NP,
+  const dim3 ge((unsigned)((w.n_items + 3) / 4));
+  if (emg.KPW <= 4 && !std::getenv("TEHMM_WIDE_EMIS_PLAIN")) {
+    const EmisTab &eml = std::getenv("TEHMM_WIDE_EMIS_NOLDS") ? emg : em;      // small tracks' rows staged in LDS
+    const size_t lds_e = (size_t)std::max(1, eml.lds_rows) * m->NP * sizeof(double);
+    if (ratio) {
+      allow_lds(k_wide_emis_fit16<true>, lds_e);
+      hipLaunchKernelGGL((k_wide_emis_fit16<true>), ge, dim3(256), lds_e, st, iv, eml, lg, m->N, NPW, m->NP,
+                         (const double *)m->lt.p, (const double *)b->ratios.p, w.E.p, w.ms.p, w.flags.p);
+    } else {
+      allow_lds(k_wide_emis_fit16<false>, lds_e);
+      hipLaunchKernelGGL((k_wide_emis_fit16<false>), ge, dim3(256), lds_e, st, iv, eml, lg, m->N, NPW, m->NP,
+                         (const double *)m->lt.p, (const double *)nullptr, w.E.p, w.ms.p, w.flags.p);
+    }
+  } else if (ratio)
+    hipLaunchKernelGGL((k_wide_emis_fit<true>), ge, dim3(256), 0, st, iv, emg, lg, m->N, NPW, m->NP,
                        (const double *)m->lt.p, (const double *)b->ratios.p, w.E.p, w.ms.p, w.flags.p);
   else
-    hipLaunchKernelGGL((k_wide_emis_fit<false>), dim3((w.n_items + 3) / 4), dim3(256), 0, st, iv, emg, lg, m->N, NPW, m->NP,
+    hipLaunchKernelGGL((k_wide_emis_fit<false>), ge, dim3(256), 0, st, iv, emg, lg, m->N, NPW, m->NP,
                        (const double *)m->lt.p, (const double *)nullptr, w.E.p, w.ms.p, w.flags.p);
   (void)hipEventRecord(b->ev[9], st);
   // warm-up: what the last E-step with this model handle needed (the parameters move a little per iteration; the links
-  // are verified whatever the guess), 128 positions to begin with
+  // are verified whatever the guess), 64 positions to begin with
   constexpr int kWuMax = 1024;
-  int Wu = 128;
+  int Wu = 64;
   if (const char *wus = std::getenv("TEHMM_LANE_WARMUP")) Wu = std::min(kWuMax, std::max(1, std::atoi(wus)));
   else if (w.wu_ok > 0 && w.wu_model == m->uid) Wu = w.wu_ok;
   int attempts = 0;
@@ -3886,7 +3992,7 @@ static int estep_wide(tehmm_model_t *m, tehmm_batch_t *b, bool ratio, double *de
   w.wu_model = m->uid;
   w.wu_version = m->version;
   (void)hipEventRecord(b->ev[6], st);
-  hipLaunchKernelGGL(k_wide_loglik, dim3((b->n + 63) / 64), dim3(64), 0, st, iv, lg, m->N, NPW, (const double *)w.end_f.p,
+  hipLaunchKernelGGL(k_wide_loglik, dim3((b->n + 3) / 4), dim3(256), 0, st, iv, lg, m->N, NPW, (const double *)w.end_f.p,
                      (const double *)w.SL.p, (const double *)w.lr.p, b->fwd_lp.p);
   int rcr = TEHMM_OK;
   switch (NPW) {

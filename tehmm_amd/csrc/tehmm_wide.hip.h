@@ -168,6 +168,11 @@ void k_wide_fwd(IntervalTab iv, LaneGeom lg, int N, int NP, int Wu, const double
     if (s == 0 && valid && t0 > 0 && len > 0) vec_out(pre);
     const double *er = E + (r0 + (act ? s : 0)) * (int64_t)NPW + kq;
     const double msv = act ? ms[r0 + s] : 0.0;
+    // the emission row is requested BEFORE the product (one wave per SIMD: nothing else hides its latency; round 3 read
+    // it behind the product, twice)
+    double ev[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) ev[k] = er[4 * k];
     lane_d4 acc[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) acc[rt] = (lane_d4){0.0, 0.0, 0.0, 0.0};
@@ -178,16 +183,18 @@ void k_wide_fwd(IntervalTab iv, LaneGeom lg, int N, int NP, int Wu, const double
       for (int k = 0; k < KS; ++k)
         if (exact && s == -wu) acc[k >> 2][k & 3] = kq + 4 * k < N ? exp(pi[kq + 4 * k]) : 0.0;
     }
-    // the emission row is read twice (sum, then scaled values) instead of being held in KS more registers
     double t = 0.0;
 #pragma unroll
-    for (int k = 0; k < KS; ++k) t += acc[k >> 2][k & 3] * (act ? er[4 * k] : 0.0);
+    for (int k = 0; k < KS; ++k) {
+      ev[k] = acc[k >> 2][k & 3] * ev[k];
+      t += act ? ev[k] : 0.0;
+    }
     t = item_sum4(t);
     const int e = ((__double2hiint(t) >> 20) & 0x7ff) - 1022;
     const double scale = __hiloint2double((1023 - e) << 20, 0);
     if (act) {
 #pragma unroll
-      for (int k = 0; k < KS; ++k) v[k] = (acc[k >> 2][k & 3] * er[4 * k]) * scale;
+      for (int k = 0; k < KS; ++k) v[k] = ev[k] * scale;
     }
     if (act && s >= 0) {
       slog += (double)e * 0.6931471805599453 + msv;
@@ -245,6 +252,20 @@ void k_wide_bwd(IntervalTab iv, LaneGeom lg, int N, int NP, int Wu, const double
     if (s == L - 1 && valid && !last) vec_out(pre);              // v = w_{t0 + L} as the warm-up left it
     const double *er = E + (r0 + (act ? s : 0)) * (int64_t)NPW + kq;
     const bool official = act && s < len;
+    // emission and alpha' rows of this step are requested BEFORE the product (one wave per SIMD: nothing else hides
+    // their latency); the alpha' row from a clamped position where the step has none
+    // (128 padded states, posterior form: the two rows do not fit the 512 registers -- they are read behind the product)
+    constexpr bool PRE_AL = ESTEP || NPW < 128;
+    double ev[KS];
+    float av[KS];
+    const float *ar = AL + wide_al_index<NPW>(tile, L, min(s, L - 1), 0, lane);
+    if (PRE_AL) {
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        ev[k] = er[4 * k];
+        av[k] = ar[(int64_t)k << 6];
+      }
+    }
     lane_d4 acc[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) acc[rt] = (lane_d4){0.0, 0.0, 0.0, 0.0};
@@ -260,11 +281,13 @@ void k_wide_bwd(IntervalTab iv, LaneGeom lg, int N, int NP, int Wu, const double
     for (int k = 0; k < KS; ++k)
       acc[k >> 2][k & 3] = s == top ? (kq + 4 * k < N ? 1.0 : 0.0) : acc[k >> 2][k & 3] * scale;
     if (s < L && official) {
-      // the alpha' row is read twice (row sum, then the values) instead of being held in registers
-      const float *ar = AL + wide_al_index<NPW>(tile, L, s, 0, lane);
-      double gt = 0.0;
+      if (!PRE_AL) {
 #pragma unroll
-      for (int k = 0; k < KS; ++k) gt += (double)ar[(int64_t)k << 6] * acc[k >> 2][k & 3];
+        for (int k = 0; k < KS; ++k) av[k] = ar[(int64_t)k << 6];
+      }
+      double gt = 0.0;                          // (the products are formed twice rather than held in KS more registers)
+#pragma unroll
+      for (int k = 0; k < KS; ++k) gt += (double)av[k] * acc[k >> 2][k & 3];
       gt = item_sum4(gt);
       const double inv = 1.0 / gt;
       if (ESTEP) {
@@ -272,19 +295,19 @@ void k_wide_bwd(IntervalTab iv, LaneGeom lg, int N, int NP, int Wu, const double
         const double wzs = scale * inv;
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
-          GAM[ix + ((int64_t)k << 6)] = (float)(((double)ar[(int64_t)k << 6] * acc[k >> 2][k & 3]) * inv);
+          GAM[ix + ((int64_t)k << 6)] = (float)(((double)av[k] * acc[k >> 2][k & 3]) * inv);
           WZ[ix + ((int64_t)k << 6)] = s == top ? 0.f : (float)(v[k] * wzs);
         }
       } else {
         double *pr = post + (r0 + s) * (int64_t)N + kq;
 #pragma unroll
         for (int k = 0; k < KS; ++k)
-          if (kq + 4 * k < N) pr[4 * k] = (((double)ar[(int64_t)k << 6] * acc[k >> 2][k & 3]) * inv + eps) * inv_epsden;
+          if (kq + 4 * k < N) pr[4 * k] = (((double)av[k] * acc[k >> 2][k & 3]) * inv + eps) * inv_epsden;
       }
     }                                 // (the four lanes of an item take the branch together: item_sum4 is safe)
     if (act) {
 #pragma unroll
-      for (int k = 0; k < KS; ++k) v[k] = er[4 * k] * acc[k >> 2][k & 3];
+      for (int k = 0; k < KS; ++k) v[k] = (PRE_AL ? ev[k] : er[4 * k]) * acc[k >> 2][k & 3];
     }
   }
   if (valid && len > 0) vec_out(end);
@@ -295,7 +318,7 @@ void k_wide_bwd(IntervalTab iv, LaneGeom lg, int N, int NP, int Wu, const double
 // flags[1] counts failed links; lr [item] = log(rho) of the forward link
 __global__ __launch_bounds__(256) void k_wide_links(IntervalTab iv, LaneGeom lg, int N, int NPW, const double *pre_f,
                                                     const double *end_f, const double *pre_b, const double *end_b,
-                                                    double *lr, int *flags) {
+                                                    double *lr, int *flags, double tol = TEHMM_FB_TOL) {
   const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= lg.n_items) return;
   const int id = lg.item_iv[item];
@@ -307,35 +330,43 @@ __global__ __launch_bounds__(256) void k_wide_links(IntervalTab iv, LaneGeom lg,
     bool bad = false;
     double rmax = -1.0, rmin = INFINITY;
     for (int j = 0; j < N; ++j) link_accum(a[j], b[j], bad, rmax, rmin);
-    const bool ok = !bad && rmax > 0.0 && rmin < INFINITY && rmax / rmin - 1.0 <= TEHMM_FB_TOL;
+    const bool ok = !bad && rmax > 0.0 && rmin < INFINITY && rmax / rmin - 1.0 <= tol;
     fails += !ok;
-    lr[item] = ok ? log(rmax) : 0.0;
+    lr[item] = ok ? 0.5 * (log(rmax) + log(rmin)) : 0.0;     // (geometric mean of the extreme ratios: no bias of one sign)
   }
   if (t0 + lg.L < T) {                                       // backward: pre_b[item] against end_b[item + 1]
     const double *a = pre_b + item * NPW, *b = end_b + (item + 1) * NPW;
     bool bad = false;
     double rmax = -1.0, rmin = INFINITY;
     for (int j = 0; j < N; ++j) link_accum(a[j], b[j], bad, rmax, rmin);
-    const bool ok = !bad && rmax > 0.0 && rmin < INFINITY && rmax / rmin - 1.0 <= TEHMM_FB_TOL;
+    const bool ok = !bad && rmax > 0.0 && rmin < INFINITY && rmax / rmin - 1.0 <= tol;
     fails += !ok;
   }
   if (fails) atomicAdd(&flags[1], fails);
 }
 
-// one thread per interval: log P = sum of the items' scale gains - the links' log(rho) + log(sum of the last vector)
-__global__ __launch_bounds__(64) void k_wide_loglik(IntervalTab iv, LaneGeom lg, int N, int NPW, const double *end_f,
+// one WAVE per interval (round 3: one thread, 0.2 ms for 20 intervals of 780 items): log P = sum of the items' scale
+// gains - the links' log(rho) + log(sum of the last vector); lane l adds the items l, l + 64, ... in order, the lanes
+// are folded in a fixed tree -- the same bits run to run
+__global__ __launch_bounds__(256) void k_wide_loglik(IntervalTab iv, LaneGeom lg, int N, int NPW, const double *end_f,
                                                     const double *SL, const double *lr, double *fwd_logprob) {
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (id >= iv.n) return;
   const int64_t T = iv.len[id];
   if (T <= 0) return;
   const int64_t i0 = lg.ifirst[id], i1 = lg.ifirst[id + 1];
   double s = 0.0;
-  for (int64_t it = i0; it < i1; ++it) s += SL[it] - lr[it];
+  for (int64_t it = i0 + lane; it < i1; it += 64) s += SL[it] - lr[it];
   double tot = 0.0;
   const double *e = end_f + (i1 - 1) * NPW;
-  for (int j = 0; j < N; ++j) tot += e[j];
-  fwd_logprob[id] = s + log(tot);
+  for (int j = lane; j < N; j += 64) tot += e[j];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    tot += __shfl_xor(tot, o);
+  }
+  if (lane == 0) fwd_logprob[id] = s + log(tot);
 }
 
 

@@ -48,6 +48,27 @@ struct WideRows {
   int grow[TEHMM_ESTEP_MAXRT * 16];      // (track, symbol) row -> row of the global statistics table
 };
 
+// Tracks with MANY symbols (the 250-bin gaussian tracks) do not go through the one-hot product -- 16 row tiles of
+// which a 16-item tile touches a few, 448 matrix instructions per position tile and track at 112 states, 5.7 of the
+// 6.3 ms of the first version at 100 states -- but are privatised in LDS as 64-bit FIXED-POINT integers (ds_add_u64 is
+// exact, hence order-free: reproducible whatever order the waves arrive in), one (track, state range) per workgroup
+// role so that [rows][states of the range] fits the 160 KB of a CU.
+struct WideLds {
+  int n_trk;                             // big tracks
+  int col[TEHMM_MAX_TRACKS];             // observation column
+  int rows[TEHMM_MAX_TRACKS];            // symbols (rows of the histogram)
+  int gbase[TEHMM_MAX_TRACKS];           // first row of the track in the global statistics table
+};
+
+// largest segment ratio of a batch (positive doubles order like their bit patterns)
+__global__ __launch_bounds__(256) void k_ratio_max(const double *__restrict__ r, int64_t n, unsigned long long *out) {
+  double m = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmax(m, r[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+
 // ---- emission rows for fit: E [row][NPW] = exp(x - max), ms [row] = max, with the segment ratios applied the way
 // fit applies them (the emission ratio comes through em.ratios, the transition term is added here) -----------------
 template <bool TRATIO>
@@ -81,6 +102,95 @@ __global__ __launch_bounds__(256) void k_wide_emis_fit(IntervalTab iv, EmisTab e
   if (bad && lane == 0) atomicAdd(&flags[0], 1);
 }
 
+// The same for at most 16 tracks (KPW <= 4 observation words per position), the form that is used: the kernel above
+// walks its item position by position behind a chain of dependent loads (observation word -> table row -> sum: 8 us
+// per position and wave, 2.0 of the 15.7 ms of the first version at 100 states).  Here the observation words (and
+// ratios) of SIXTEEN positions are one coalesced load, a position's symbols reach the table-row addresses through
+// v_readlane (they are wave-uniform), and the gathers of two positions are in flight together.
+template <bool TRATIO>
+__global__ __launch_bounds__(256) void k_wide_emis_fit16(IntervalTab iv, EmisTab em, LaneGeom lg, int N, int NPW, int NP,
+                                                         const double *__restrict__ g_lt, const double *__restrict__ tratios,
+                                                         double *E, double *ms, int *flags) {
+  // the rows of the small tracks are staged in LDS (em.ldsbase, as in the cooperative kernels): gathered from L2 every
+  // table row is 512 bytes per position and track whatever N is -- 23 GB per E-step over 5 Mb at 12 tracks, which is
+  // what the first version of this kernel spent its 3.2 ms on
+  extern __shared__ double emis_ltab[];
+  for (int i = threadIdx.x; i < em.lds_rows * NP; i += blockDim.x) emis_ltab[i] = em.ltab_src[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= lg.n_items) return;
+  const int id = lg.item_iv[item];
+  const int64_t t0 = lg.item_t0[item], T = iv.len[id], p0 = iv.pos0[id], r0 = iv.out0[id];
+  const int len = (int)min((int64_t)lg.L, T - t0);
+  const double ltd0 = lane < N ? g_lt[(size_t)lane * NP + lane] : 0.0;
+  const double ltd1 = lane + 64 < N ? g_lt[(size_t)(lane + 64) * NP + lane + 64] : 0.0;
+  const int KPW = em.KPW, K = em.K;
+  const int lp = lane / KPW, ld = lane - lp * KPW;                   // this lane's (position of the block, word)
+  const int j0 = lane < N ? lane : 0, j1 = lane + 64 < N ? lane + 64 : 0;
+  const bool two = N > 64;
+  const bool eratio = em.ratios != nullptr;
+  // track k's table info in lane k, read back with v_readlane (from the kernel arguments every use is a scalar load
+  // the gathers wait for: 15 per position)
+  const int lk = min(lane, K - 1);
+  const int ti_cnt = em.rowcnt[lk], ti_lb = em.ldsbase[lk], ti_rb = em.rowbase[lk];
+  bool bad = false;
+  for (int s0 = 0; s0 < len; s0 += 16) {
+    const int nb = min(16, len - s0);
+    const int64_t g0 = p0 + t0 + s0;
+    const uint32_t ow = lp < nb ? em.obs32[(g0 + lp) * KPW + ld] : 0u;
+    double rv = 1.0;
+    if (TRATIO || eratio) rv = (lane < nb) ? (TRATIO ? tratios : em.ratios)[g0 + lane] : 1.0;
+    for (int p = 0; p < nb; p += 2) {
+      // two positions per iteration (the second one clamped at the block's end and dropped): their gathers are issued
+      // together
+      const int pq[2] = {p, min(p + 1, nb - 1)};
+      double x0[2] = {0.0, 0.0}, x1[2] = {0.0, 0.0};
+      for (int k0 = 0; k0 < K; k0 += 4) {
+        double v0[2][4], v1[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint32_t wd = (uint32_t)__builtin_amdgcn_readlane((int)ow, pq[h] * KPW + (k0 >> 2));
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int k = min(k0 + u, K - 1);
+            const int sym = (int)((wd >> (u * 8)) & 0xffu);
+            const bool inr = sym < __builtin_amdgcn_readlane(ti_cnt, k);
+            const int lb = __builtin_amdgcn_readlane(ti_lb, k);
+            const double *tr = lb >= 0 ? emis_ltab + (inr ? lb + sym : em.lds_zero) * NP
+                                       : em.tab + (int64_t)(inr ? __builtin_amdgcn_readlane(ti_rb, k) + sym : em.zero_row) * NP;
+            v0[h][u] = tr[j0];
+            v1[h][u] = two ? tr[j1] : 0.0;
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (k0 + u < K) { x0[h] += v0[h][u]; x1[h] += v1[h][u]; }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h == 1 && p + 1 >= nb) break;
+        double xa = x0[h] * em.normalize, xb = x1[h] * em.normalize;
+        const double r = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rv), pq[h]),
+                                          __builtin_amdgcn_readlane(__double2loint(rv), pq[h]));
+        if (eratio) { xa *= r; xb *= r; }
+        if (TRATIO && r > 1.) { xa += ltd0 * (r - 1.); xb += ltd1 * (r - 1.); }
+        double x[2] = {xa, xb};
+        const double m = row_max<2>(x, lane, N);
+        const bool good = m > -1e20;
+        bad = bad | !good;
+        double *dst = E + (r0 + t0 + s0 + pq[h]) * (int64_t)NPW;
+        if (lane < NPW) dst[lane] = (good && lane < N) ? exp_nonpos(xa - m) : 0.0;
+        if (lane + 64 < NPW) dst[lane + 64] = (good && lane + 64 < N) ? exp_nonpos(xb - m) : 0.0;
+        if (lane == 0) ms[r0 + t0 + s0 + pq[h]] = good ? m : 0.0;
+      }
+    }
+  }
+  if (bad && lane == 0) atomicAdd(&flags[0], 1);
+}
+
 template <int NPW>
 struct WideEstepGeom {
   static constexpr int RT = NPW / 16;                        // state tiles
@@ -109,7 +219,7 @@ __device__ __forceinline__ int wide_tile_nsmax(const IntervalTab &iv, const Lane
 // ------------------------------------------------------------------------------------------
 template <int NPW>
 __global__ __launch_bounds__(256) void k_wide_estep_xi(IntervalTab iv, LaneGeom lg, const float *__restrict__ AL,
-                                                       const float *__restrict__ WZ, double *part) {
+                                                       const float *__restrict__ WZ, double *part, int SQ) {
   using G = WideEstepGeom<NPW>;
   constexpr int RT = G::RT, RSPLIT = G::RSPLIT, RPW = G::RPW, TPW = G::TPW;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -122,9 +232,13 @@ __global__ __launch_bounds__(256) void k_wide_estep_xi(IntervalTab iv, LaneGeom 
     for (int tb = 0; tb < RT; ++tb) acc[r][tb] = (lane_d4){0.0, 0.0, 0.0, 0.0};
   const int64_t n_tiles = ((int64_t)lg.n_items + 15) / 16;
   const float4 *al4 = (const float4 *)AL, *wz4 = (const float4 *)WZ;
-  for (int64_t tile = (int64_t)blockIdx.x * TPW + tsel; tile < n_tiles; tile += (int64_t)gridDim.x * TPW) {
-    const int nsmax = wide_tile_nsmax(iv, lg, tile, lane);
-    if (nsmax <= 0) continue;
+  // work unit = (item tile, one of SQ position ranges of L / SQ): a 2 Mb batch has fewer item tiles than the GPU has SIMDs
+  const int LQ = lg.L / SQ;
+  for (int64_t unit = (int64_t)blockIdx.x * TPW + tsel; unit < n_tiles * SQ; unit += (int64_t)gridDim.x * TPW) {
+    const int64_t tile = unit / SQ;
+    const int s_lo = (int)(unit - tile * SQ) * LQ;
+    const int nsmax = min(wide_tile_nsmax(iv, lg, tile, lane), s_lo + LQ);
+    if (nsmax <= s_lo) continue;
     // float4 (tile, s, state, k4) = ((tile L + s) NPW + state) 4 + k4
     const int64_t b4 = tile * lg.L * (int64_t)(NPW * 4) + m * 4 + k4;
     float4 xa[RPW], xw[RT];
@@ -137,8 +251,8 @@ __global__ __launch_bounds__(256) void k_wide_estep_xi(IntervalTab iv, LaneGeom 
 #pragma unroll
       for (int tb = 0; tb < RT; ++tb) xw[tb] = wz4[b4 + ((int64_t)s * NPW + 16 * tb) * 4];
     };
-    request(0);
-    for (int s = 0; s < nsmax; ++s) {
+    request(s_lo);
+    for (int s = s_lo; s < nsmax; ++s) {
       double a[RPW][4], w[RT][4];
 #pragma unroll
       for (int r = 0; r < RPW; ++r) {
@@ -183,7 +297,7 @@ __global__ __launch_bounds__(256) void k_wide_estep_xi(IntervalTab iv, LaneGeom 
 template <int NPW, bool RATIO>
 __global__ __launch_bounds__(256) void k_wide_estep_rows(IntervalTab iv, LaneGeom lg, const WideRows *__restrict__ wr, int KP,
                                                          const uint8_t *__restrict__ obs, const double *__restrict__ ratios,
-                                                         const float *__restrict__ GAM, double *part) {
+                                                         const float *__restrict__ GAM, double *part, int SQ) {
   constexpr int RT = NPW / 16;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int m = lane & 15, k4 = lane >> 4;
@@ -198,7 +312,10 @@ __global__ __launch_bounds__(256) void k_wide_estep_rows(IntervalTab iv, LaneGeo
   for (int tb = 0; tb < RT; ++tb) acc[tb] = (lane_d4){0.0, 0.0, 0.0, 0.0};
   const int64_t n_tiles = ((int64_t)lg.n_items + 15) / 16;
   const float4 *gam4 = (const float4 *)GAM;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  const int LQ = lg.L / SQ;
+  for (int64_t unit = blockIdx.x; unit < n_tiles * SQ; unit += gridDim.x) {
+    const int64_t tile = unit / SQ;
+    const int s_lo = (int)(unit - tile * SQ) * LQ;
     // the lane's four items 4 k4 + kk: observation rows, ratios, lengths
     int64_t oo[4], rp[4], t0k[4];
     int nsk[4], nsmax = 0;
@@ -217,42 +334,53 @@ __global__ __launch_bounds__(256) void k_wide_estep_rows(IntervalTab iv, LaneGeo
     }
     nsmax = max(nsmax, __shfl_xor(nsmax, 16));
     nsmax = max(nsmax, __shfl_xor(nsmax, 32));
-    nsmax = __builtin_amdgcn_readfirstlane(nsmax);
-    if (nsmax <= 0) continue;
+    nsmax = min(__builtin_amdgcn_readfirstlane(nsmax), s_lo + LQ);
+    if (nsmax <= s_lo) continue;
     const int64_t b4 = tile * lg.L * (int64_t)(NPW * 4) + m * 4 + k4;
-    float4 xg[RT];
-    int sy[4];
-    double rr[4];
-    auto request = [&](int s) {
+    // TWO steps are on their way at any time (buffers 0 / 1): with one, the matrix instructions of a step (0.75 us)
+    // were all that covered the latency of the next step's rows -- 4 us per step at two waves per SIMD
+    float4 xg[2][RT];
+    int sy[2][4];
+    double rr[2][4];
+    auto request = [&](int s, auto bsel) {
+      constexpr int B = decltype(bsel)::value;
 #pragma unroll
-      for (int tb = 0; tb < RT; ++tb) xg[tb] = gam4[b4 + ((int64_t)s * NPW + 16 * tb) * 4];
+      for (int tb = 0; tb < RT; ++tb) xg[B][tb] = gam4[b4 + ((int64_t)s * NPW + 16 * tb) * 4];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const int sc = max(0, min(s, nsk[kk] - 1));           // unconditional loads from inside the item
-        sy[kk] = (int)obs[oo[kk] + (int64_t)sc * KP];
-        rr[kk] = RATIO ? ratios[rp[kk] + sc] : 1.0;
+        sy[B][kk] = (int)obs[oo[kk] + (int64_t)sc * KP];
+        rr[B][kk] = RATIO ? ratios[rp[kk] + sc] : 1.0;
       }
     };
-    request(0);
-    for (int s = 0; s < nsmax; ++s) {
+    auto step = [&](int s, auto bsel) {
+      constexpr int B = decltype(bsel)::value;
       double a[4], g[RT][4];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        const double r = rr[kk];
-        double v = (sy[kk] == rsym) ? r : 0.0;                                        // kind 0 (rsym = -1 otherwise)
+        const double r = rr[B][kk];
+        double v = (sy[B][kk] == rsym) ? r : 0.0;                                     // kind 0 (rsym = -1 otherwise)
         v = kind == 1 ? ((s == 0 && t0k[kk] == 0) ? 1.0 : 0.0) : v;
         v = kind == 2 ? ((RATIO && r > 1. && t0k[kk] + s > 0) ? r - 1. : 0.0) : v;
         a[kk] = s < nsk[kk] ? v : 0.0;
       }
 #pragma unroll
       for (int tb = 0; tb < RT; ++tb) {
-        g[tb][0] = (double)xg[tb].x; g[tb][1] = (double)xg[tb].y; g[tb][2] = (double)xg[tb].z; g[tb][3] = (double)xg[tb].w;
+        g[tb][0] = (double)xg[B][tb].x; g[tb][1] = (double)xg[B][tb].y; g[tb][2] = (double)xg[B][tb].z; g[tb][3] = (double)xg[B][tb].w;
       }
-      if (s + 1 < nsmax) request(s + 1);
+      if (s + 2 < nsmax) request(s + 2, bsel);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
         for (int tb = 0; tb < RT; ++tb) acc[tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], g[tb][kk], acc[tb], 0, 0, 0);
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    request(s_lo, B0{});
+    if (s_lo + 1 < nsmax) request(s_lo + 1, B1{});
+    for (int s = s_lo; s < nsmax; s += 2) {
+      step(s, B0{});
+      if (s + 1 < nsmax) step(s + 1, B1{});
     }
   }
   double *slot = part + (size_t)blockIdx.x * (size_t)(nrt * 16) * NPW;
@@ -262,14 +390,117 @@ __global__ __launch_bounds__(256) void k_wide_estep_rows(IntervalTab iv, LaneGeo
     for (int q = 0; q < 4; ++q) slot[(size_t)(rt * 16 + 4 * q + k4) * NPW + 16 * tb + m] = acc[tb][q];
 }
 
+// ------------------------------------------------------------------------------------------
+// Emission histograms of the tracks with many symbols: hist [rows][HS] fixed-point in LDS, HS = NPW / NSPLIT states.
+// grid (x = persistent workgroups over the item tiles, y = track * NSPLIT + state range), block = 512 (8 waves, one
+// item tile each).  Lane = (state sub-index lane >> 4, item lane & 15): one load covers four states of the 16 items.
+// part: per y, [gridDim.x slots][rows][HS] behind the y before it.
+// ------------------------------------------------------------------------------------------
+template <int NPW, int NSPLIT, bool RATIO>
+__global__ __launch_bounds__(512) void k_wide_estep_hist_lds(IntervalTab iv, LaneGeom lg, const WideLds *__restrict__ wl, int N,
+                                                             int KP, const uint8_t *__restrict__ obs,
+                                                             const double *__restrict__ ratios, const float *__restrict__ GAM,
+                                                             double *part, int shift, int SQ) {
+  constexpr int HS = NPW / NSPLIT, HQ = HS / 4;
+  extern __shared__ unsigned long long wide_hist[];
+  const int trk = blockIdx.y / NSPLIT, j0 = (blockIdx.y % NSPLIT) * HS;
+  const int col = wl->col[trk], rows = wl->rows[trk];
+  for (int i = threadIdx.x; i < rows * HS; i += blockDim.x) wide_hist[i] = 0ull;
+  __syncthreads();
+  const double fscale = ldexp(1.0, shift), finv = ldexp(1.0, -shift);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int kq = lane >> 4, i16 = lane & 15;
+  const int64_t n_tiles = ((int64_t)lg.n_items + 15) / 16;
+  const int LQ = lg.L / SQ;
+  for (int64_t unit = (int64_t)blockIdx.x * 8 + wv; unit < n_tiles * SQ; unit += (int64_t)gridDim.x * 8) {
+    const int64_t tile = unit / SQ;
+    const int s_lo = (int)(unit - tile * SQ) * LQ;
+    const int64_t item = tile * 16 + i16;
+    const bool valid = item < lg.n_items;
+    const int64_t itc = valid ? item : (int64_t)lg.n_items - 1;
+    const int id = lg.item_iv[itc];
+    const int64_t t0 = lg.item_t0[itc];
+    const int ns = valid ? (int)min((int64_t)lg.L, iv.len[id] - t0) : 0;
+    int nsmax = ns;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) nsmax = max(nsmax, __shfl_xor(nsmax, o));
+    nsmax = min(__builtin_amdgcn_readfirstlane(nsmax), s_lo + LQ);
+    if (nsmax <= s_lo) continue;
+    const int64_t pos = iv.pos0[id] + t0;
+    const uint8_t *op = obs + pos * KP + col;
+    const float *gp = GAM + (tile * lg.L * (int64_t)NPW + j0 + kq) * 16 + i16;       // + (s NPW + 4 i) 16
+    float gn[HQ];
+    int syn;
+    double rn;
+    auto request = [&](int s) {
+      const int sc = max(0, min(s, ns - 1));                 // unconditional loads from inside the item
+#pragma unroll
+      for (int i = 0; i < HQ; ++i) gn[i] = gp[((int64_t)s * NPW + 4 * i) * 16];
+      syn = (int)op[(int64_t)sc * KP];
+      rn = RATIO ? ratios[pos + sc] : 1.0;
+    };
+    request(s_lo);
+    for (int s = s_lo; s < nsmax; ++s) {
+      float gc[HQ];
+#pragma unroll
+      for (int i = 0; i < HQ; ++i) gc[i] = gn[i];
+      const int sym = syn;
+      const double f = rn * fscale;
+      if (s + 1 < nsmax) request(s + 1);
+      // (a symbol beyond the track's last one lands in the reference's padding cells, which emission.maximize never
+      //  reads: not booked)
+      if (s < ns && sym < rows) {
+        unsigned long long *hr = wide_hist + (size_t)sym * HS + kq;
+#pragma unroll
+        for (int i = 0; i < HQ; ++i)
+        {
+          // (posteriors are sparse: most states of a position hold nothing at the histogram's resolution, and adding an
+          //  exact zero is no addition)
+          const long long q = __double2ll_rn((double)gc[i] * f);
+          if (q != 0 && j0 + 4 * i + kq < N) atomicAdd(hr + 4 * i, (unsigned long long)q);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  size_t goff = 0;
+  for (int y = 0; y < (int)blockIdx.y; ++y) goff += (size_t)gridDim.x * wl->rows[y / NSPLIT] * HS;
+  double *slot = part + goff + (size_t)blockIdx.x * rows * HS;
+  for (int i = threadIdx.x; i < rows * HS; i += blockDim.x) slot[i] = (double)(long long)wide_hist[i] * finv;
+}
+
+// grid (x over the cells of the largest track, y = track * nsplit + state range)
+__global__ __launch_bounds__(256) void k_wide_fold_lds(const double *__restrict__ part, int nslot, int N, int NP, int HS, int nsplit,
+                                                       const WideLds *__restrict__ wl, double *gstat) {
+  const int trk = blockIdx.y / nsplit, j0 = (blockIdx.y % nsplit) * HS;
+  const int rows = wl->rows[trk];
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * HS) return;
+  const int lrow = idx / HS, j = j0 + idx - lrow * HS;
+  if (j >= N) return;
+  size_t goff = 0;
+  for (int y = 0; y < (int)blockIdx.y; ++y) goff += (size_t)nslot * wl->rows[y / nsplit] * HS;
+  double sum = 0.0;
+  for (int s = 0; s < nslot; ++s) sum += part[goff + (size_t)s * rows * HS + idx];
+  gstat[(int64_t)(wl->gbase[trk] + lrow) * NP + j] += sum;
+}
+
 // ---- the ordered sums over the writers' slots (one thread per cell, slots ascending) ----------------------------
 __global__ __launch_bounds__(256) void k_wide_fold_xi(const double *__restrict__ part, int nslot, int N, int NPW, int NP, double *gC) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= N * N) return;
   const int i = idx / N, j = idx - i * N;
-  double sum = 0.0;
-  for (int s = 0; s < nslot; ++s) sum += part[(size_t)s * NPW * NPW + (size_t)i * NPW + j];
-  gC[(size_t)i * NP + j] += sum;
+  // eight interleaved running sums (slots s = u mod 8), combined in a fixed order: still one order of additions per
+  // cell, with eight loads in flight instead of one
+  double ps[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  const double *src = part + (size_t)i * NPW + j;
+  int s = 0;
+  for (; s + 8 <= nslot; s += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ps[u] += src[(size_t)(s + u) * NPW * NPW];
+  }
+  for (int u = 0; s + u < nslot; ++u) ps[u] += src[(size_t)(s + u) * NPW * NPW];
+  gC[(size_t)i * NP + j] += ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
 }
 __global__ __launch_bounds__(256) void k_wide_fold_rows(const double *__restrict__ part, int nslot, int N, int NPW, int NP,
                                                         const WideRows *__restrict__ wr, double *gstat, double *gstart, double *gD) {
@@ -279,8 +510,16 @@ __global__ __launch_bounds__(256) void k_wide_fold_rows(const double *__restrict
   const int row = idx / N, j = idx - row * N;
   const int inf = wr->info[row];
   if (inf < 0) return;
-  double sum = 0.0;
-  for (int s = 0; s < nslot; ++s) sum += part[((size_t)s * nrow + row) * NPW + j];
+  double ps[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // (eight interleaved running sums, fixed order: see k_wide_fold_xi)
+  const double *src = part + (size_t)row * NPW + j;
+  const size_t stride = (size_t)nrow * NPW;
+  int s = 0;
+  for (; s + 8 <= nslot; s += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ps[u] += src[(size_t)(s + u) * stride];
+  }
+  for (int u = 0; s + u < nslot; ++u) ps[u] += src[(size_t)(s + u) * stride];
+  const double sum = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
   if (inf == TEHMM_WIDE_ROW_START) gstart[j] += sum;
   else if (inf == TEHMM_WIDE_ROW_DIAG) gD[j] += sum;
   else gstat[(int64_t)wr->grow[row] * NP + j] += sum;
