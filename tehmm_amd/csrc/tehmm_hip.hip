@@ -716,7 +716,9 @@ int tehmm_model_create(int N, int K, int S, const double *lt, const double *pi,
     R += cnt;
   }
   m->R = R;
-  std::vector<double> htab((size_t)(R + 1) * NP, 0.0);     // row R: the zero padding (EmisTab::zero_row)
+  // row R: the zero padding (EmisTab::zero_row); 128 doubles of slack behind it (k_wide_emis_tile reads a row up to
+  // state NPW - 1 <= 127 whatever NP is)
+  std::vector<double> htab((size_t)(R + 1) * NP + 128, 0.0);
   for (int k = 0; k < K; ++k)
     for (int s = 0; s < m->rowcnt[k]; ++s)
       for (int j = 0; j < N; ++j)
@@ -2029,6 +2031,60 @@ static int posterior_wide_finish(tehmm_batch *b, const tehmm_model *m, const Int
   return TEHMM_OK;
 }
 
+// emission rows of the item-parallel passes in the tile layout (k_wide_emis_tile): mode 0 tables, 1 from the log rows
+// of the exact Viterbi, 2 fit, 3 fit with segment ratios
+template <int NPW>
+static void launch_wide_emis_npw(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em_in, const LaneGeom &lg,
+                                 int mode, const double *log_rows, hipStream_t st) {
+  WideWork &w = b->ww;
+  // this kernel's own LDS assignment: smallest tracks first while they fit 64 KB (two workgroups per CU)
+  EmisTab em = em_in;
+  {
+    const size_t budget_rows = (size_t)(64 * 1024) / ((size_t)m->NP * sizeof(double));
+    std::vector<int> ord((size_t)m->K);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int c) { return m->rowcnt[a] < m->rowcnt[c]; });
+    for (int k = 0; k < TEHMM_MAX_TRACKS; ++k) em.ldsbase[k] = -1;
+    int used = 0;
+    for (int k : ord) {
+      if ((size_t)(used + m->rowcnt[k] + 1) > budget_rows) break;
+      em.ldsbase[k] = used;
+      used += m->rowcnt[k];
+    }
+    em.lds_zero = used;
+    em.lds_rows = used + 1;
+  }
+  const int64_t n_tiles = ((int64_t)w.n_items + 15) / 16, units = n_tiles * ((w.L + 15) / 16);
+  const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((units + 3) / 4, 2048)));
+  const size_t lds = ((size_t)(mode == 1 ? 0 : std::max(1, em.lds_rows)) * m->NP + NPW) * sizeof(double) + (size_t)3 * m->K * sizeof(int) + 16;
+#define EMIS(MODE_)                                                                                                   \
+  do {                                                                                                                \
+    allow_lds(k_wide_emis_tile<NPW, MODE_>, lds);                                                                     \
+    hipLaunchKernelGGL((k_wide_emis_tile<NPW, MODE_>), grid, dim3(256), lds, st, iv, em, lg, m->N, m->NP,             \
+                       (const double *)m->lt.p, (const double *)b->ratios.p, log_rows, w.E.p, w.ms.p, w.flags.p);     \
+  } while (0)
+  switch (mode) {
+    case 0: EMIS(0); break;
+    case 1: EMIS(1); break;
+    case 2: EMIS(2); break;
+    default: EMIS(3); break;
+  }
+#undef EMIS
+}
+static void launch_wide_emis(tehmm_batch *b, const tehmm_model *m, const IntervalTab &iv, const EmisTab &em, const LaneGeom &lg,
+                             int mode, const double *log_rows, hipStream_t st) {
+  switch (b->ww.NPW) {
+    case 16: launch_wide_emis_npw<16>(b, m, iv, em, lg, mode, log_rows, st); break;
+    case 32: launch_wide_emis_npw<32>(b, m, iv, em, lg, mode, log_rows, st); break;
+    case 48: launch_wide_emis_npw<48>(b, m, iv, em, lg, mode, log_rows, st); break;
+    case 64: launch_wide_emis_npw<64>(b, m, iv, em, lg, mode, log_rows, st); break;
+    case 80: launch_wide_emis_npw<80>(b, m, iv, em, lg, mode, log_rows, st); break;
+    case 96: launch_wide_emis_npw<96>(b, m, iv, em, lg, mode, log_rows, st); break;
+    case 112: launch_wide_emis_npw<112>(b, m, iv, em, lg, mode, log_rows, st); break;
+    default: launch_wide_emis_npw<128>(b, m, iv, em, lg, mode, log_rows, st); break;
+  }
+}
+
 // Item geometry and workspaces of the item-parallel passes for (NPW, L); *fits = false: not enough device memory
 // (nothing changed).  The alpha' rows are (re)allocated here: al_zeroed tells the E-step whether the slots no pass
 // writes have been cleared since.
@@ -2061,8 +2117,8 @@ static int wide_geometry(tehmm_batch *b, int NPW, int L, bool *fits) {
     HIPCHK(w.item_t0.upload(h_t0.data(), h_t0.size()));
     HIPCHK(w.ifirst.upload(h_first.data(), h_first.size()));
     const size_t ni = (size_t)std::max(1, w.n_groups) * 64;
-    HIPCHK(w.E.alloc((size_t)b->total * NPW + 1));
-    HIPCHK(w.ms.alloc((size_t)b->total + 1));
+    HIPCHK(w.E.alloc(ni * L * NPW));           // tile layout (wide_e_row): items padded to whole tiles
+    HIPCHK(w.ms.alloc(ni * L));
     HIPCHK(w.AL.alloc(ni * L * (NPW / 4) * 4));
     for (DBuf<double> *d : {&w.pre_f, &w.end_f, &w.pre_b, &w.end_b}) HIPCHK(d->alloc(ni * NPW));
     HIPCHK(w.SL.alloc(ni));
@@ -2101,13 +2157,9 @@ static int posterior_wide_cp(tehmm_batch *b, const tehmm_model *m, const Interva
   LaneGeom lg;
   lg.item_iv = w.item_iv.p; lg.item_t0 = w.item_t0.p; lg.ifirst = w.ifirst.p;
   lg.n_items = w.n_items; lg.n_groups = w.n_groups; lg.L = L;
-  const EmisTab emg = without_lds_tables(em);
   HIPCHK(hipMemsetAsync(w.flags.p, 0, 4 * sizeof(int), st));
-  if (log_rows)      // the exact Viterbi of this evaluation has the log rows already (k_wide_logrows): no second gather
-    hipLaunchKernelGGL(k_wide_emis_from_log, dim3((w.n_items + 3) / 4), dim3(256), 0, st, iv, lg, m->N, NPW, log_rows, w.E.p, w.ms.p,
-                       w.flags.p);
-  else
-    hipLaunchKernelGGL(k_wide_emis, dim3((w.n_items + 3) / 4), dim3(256), 0, st, iv, emg, lg, m->N, NPW, w.E.p, w.ms.p, w.flags.p);
+  // (log_rows: the exact Viterbi of this evaluation has the log rows already (k_wide_logrows): no second gather)
+  launch_wide_emis(b, m, iv, em, lg, log_rows ? 1 : 0, log_rows, st);
   // warm-up: 128 positions to begin with (it may exceed the item length: the passes read the emission rows of the
   // interval, not of the item), or what the last evaluation with this model needed
   constexpr int kWuMax = 1024;
@@ -3936,7 +3988,6 @@ static int estep_wide(tehmm_model_t *m, tehmm_batch_t *b, bool ratio, double *de
   IntervalTab iv;
   EmisTab em;
   fill_tabs(m, b, iv, em, ratio);     // fit applies the ratios to emissions too (basehmm.py:510)
-  const EmisTab emg = without_lds_tables(em);
   LaneGeom lg;
   lg.item_iv = w.item_iv.p; lg.item_t0 = w.item_t0.p; lg.ifirst = w.ifirst.p;
   lg.n_items = w.n_items; lg.n_groups = w.n_groups; lg.L = L;
@@ -3946,25 +3997,7 @@ static int estep_wide(tehmm_model_t *m, tehmm_batch_t *b, bool ratio, double *de
   b->tms.clear();
   (void)hipEventRecord(b->ev[10], st);
   HIPCHK(hipMemsetAsync(w.flags.p, 0, 4 * sizeof(int), st));
-  const dim3 ge((unsigned)((w.n_items + 3) / 4));
-  if (emg.KPW <= 4 && !std::getenv("TEHMM_WIDE_EMIS_PLAIN")) {
-    const EmisTab &eml = std::getenv("TEHMM_WIDE_EMIS_NOLDS") ? emg : em;      // small tracks' rows staged in LDS
-    const size_t lds_e = (size_t)std::max(1, eml.lds_rows) * m->NP * sizeof(double);
-    if (ratio) {
-      allow_lds(k_wide_emis_fit16<true>, lds_e);
-      hipLaunchKernelGGL((k_wide_emis_fit16<true>), ge, dim3(256), lds_e, st, iv, eml, lg, m->N, NPW, m->NP,
-                         (const double *)m->lt.p, (const double *)b->ratios.p, w.E.p, w.ms.p, w.flags.p);
-    } else {
-      allow_lds(k_wide_emis_fit16<false>, lds_e);
-      hipLaunchKernelGGL((k_wide_emis_fit16<false>), ge, dim3(256), lds_e, st, iv, eml, lg, m->N, NPW, m->NP,
-                         (const double *)m->lt.p, (const double *)nullptr, w.E.p, w.ms.p, w.flags.p);
-    }
-  } else if (ratio)
-    hipLaunchKernelGGL((k_wide_emis_fit<true>), ge, dim3(256), 0, st, iv, emg, lg, m->N, NPW, m->NP,
-                       (const double *)m->lt.p, (const double *)b->ratios.p, w.E.p, w.ms.p, w.flags.p);
-  else
-    hipLaunchKernelGGL((k_wide_emis_fit<false>), ge, dim3(256), 0, st, iv, emg, lg, m->N, NPW, m->NP,
-                       (const double *)m->lt.p, (const double *)nullptr, w.E.p, w.ms.p, w.flags.p);
+  launch_wide_emis(b, m, iv, em, lg, ratio ? 3 : 2, nullptr, st);
   (void)hipEventRecord(b->ev[9], st);
   // warm-up: what the last E-step with this model handle needed (the parameters move a little per iteration; the links
   // are verified whatever the guess), 64 positions to begin with

@@ -36,54 +36,155 @@ struct WideGeom {
   static constexpr size_t FRAG_BYTES = (size_t)RT * KS * 64 * sizeof(double);
 };
 
-// ---- emission rows: E [row][NPW] = exp(x - max) (pads 0), ms [row] = max; row = user row (out0 + t) ------------
-// one wave per item, lane = state pair (j, j + 64); flags[0] counts rows no state can emit
-__global__ __launch_bounds__(256) void k_wide_emis(IntervalTab iv, EmisTab em, LaneGeom lg, int N, int NPW, double *E,
-                                                   double *ms, int *flags) {
-  const int lane = threadIdx.x & 63;
-  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (item >= lg.n_items) return;
-  const int id = lg.item_iv[item];
-  const int64_t t0 = lg.item_t0[item], T = iv.len[id], p0 = iv.pos0[id], r0 = iv.out0[id];
-  const int len = (int)min((int64_t)lg.L, T - t0);
-  bool bad = false;
-  for (int s = 0; s < len; ++s) {
-    double x[2];
-    emis_log_wide(em, em.tab, p0 + t0 + s, lane, N, x);        // (no LDS copy of the small tracks: ldsbase < 0 everywhere)
-    const double m = row_max<2>(x, lane, N);
-    const bool good = m > -1e20;
-    bad = bad | !good;
-    double *dst = E + (r0 + t0 + s) * (int64_t)NPW;
-    dst[lane] = (good && lane < N) ? exp_nonpos(x[0] - m) : 0.0;
-    if (lane + 64 < NPW) dst[lane + 64] = (good && lane + 64 < N) ? exp_nonpos(x[1] - m) : 0.0;
-    if (lane == 0) ms[r0 + t0 + s] = good ? m : 0.0;
-  }
-  if (bad && lane == 0) atomicAdd(&flags[0], 1);
+// ---- emission rows in the TILE layout ----------------------------------------------------------------------------
+// E element (item, position s of the item, state kq + 4 k) at wide_e_row(item, L, s) + k 64 + kq 16: per (16-item
+// tile, position) a dense [state][item] matrix of doubles, the layout of the alpha' rows (wide_al_index) -- the passes
+// read a row with one coalesced 512-byte load per k.  ms [(tile L + s) 16 + item & 15] = the row's maximum.
+// (Rounds 3 / 4a kept E as [user row][NPW], written by a lane = state kernel that walked an item position by position
+//  behind ~480 mostly scalar instructions per position -- symbol decode and table-row addresses are per POSITION work --
+//  1.7 ms per 2 Mb at 100 states, 3.4 ms per 5 Mb at 35; the passes then read it 32 bytes per lane group.)
+template <int NPW>
+__device__ __forceinline__ int64_t wide_e_row(int64_t item, int L, int s) {
+  return ((((item >> 4) * L + s) * WideGeom<NPW>::KS) << 6) + (item & 15);
 }
-
-// The same from the log rows the exact Viterbi of the same evaluation has already written (k_wide_logrows: BL [internal
-// position][128]): both results requested -> the ten table gathers per position are done once.
-__global__ __launch_bounds__(256) void k_wide_emis_from_log(IntervalTab iv, LaneGeom lg, int N, int NPW,
-                                                            const double *__restrict__ BL, double *E, double *ms, int *flags) {
-  const int lane = threadIdx.x & 63;
-  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (item >= lg.n_items) return;
-  const int id = lg.item_iv[item];
-  const int64_t t0 = lg.item_t0[item], T = iv.len[id], p0 = iv.pos0[id], r0 = iv.out0[id];
-  const int len = (int)min((int64_t)lg.L, T - t0);
-  bool bad = false;
-  for (int s = 0; s < len; ++s) {
-    const double *src = BL + (p0 + t0 + s) * TEHMM_WIDE_S;
-    double x[2] = {src[lane], src[lane + 64]};
-    const double m = row_max<2>(x, lane, N);
-    const bool good = m > -1e20;
-    bad = bad | !good;
-    double *dst = E + (r0 + t0 + s) * (int64_t)NPW;
-    dst[lane] = (good && lane < N) ? exp_nonpos(x[0] - m) : 0.0;
-    if (lane + 64 < NPW) dst[lane + 64] = (good && lane + 64 < N) ? exp_nonpos(x[1] - m) : 0.0;
-    if (lane == 0) ms[r0 + t0 + s] = good ? m : 0.0;
+// position s (relative to `item`, may lie before or behind it inside the same interval) = row s2 of item it2
+__device__ __forceinline__ void wide_e_start(int64_t item, int L, int s, int64_t &it2, int &s2) {
+  const int d = s >= 0 ? s / L : -((-s + L - 1) / L);
+  it2 = item + d;
+  s2 = s - d * L;
+}
+// The emission kernel in the lane mapping of the passes: lane = (item of a 16-item tile, state quarter kq), a lane
+// holds the states kq + 4 k of ITS item's position.  Per track the symbol is per-lane data (one byte extract), the
+// table row one base address, and the row's KS values KS loads at immediate offsets + KS additions: ~80 instructions
+// per position instead of ~480.  Small tracks' rows and the diagonal of the transition matrix are staged in LDS.
+//   MODE 0: tables (posterior: no ratios);  MODE 1: from the log rows BL [internal position][128] the exact Viterbi of
+//   the same evaluation has written;  MODE 2: fit without ratios;  MODE 3: fit with segment ratios (emission rows
+//   scaled by r_t, emission.py:195-196; + lt[j][j] (r_t - 1) where r_t > 1, _hmm.pyx:131-140).
+// grid = persistent workgroups over units of (tile, 16 positions); block = 256 (one unit per wave at a time).
+// LDS: ltab [lds_rows][NP] | ltd [NPW] | tinfo [3][K].  flags[0] counts units with a row no state can emit.
+template <int NPW, int MODE>
+__global__ __launch_bounds__(256) void k_wide_emis_tile(IntervalTab iv, EmisTab em, LaneGeom lg, int N, int NP,
+                                                        const double *__restrict__ g_lt, const double *__restrict__ tratios,
+                                                        const double *__restrict__ BL, double *E, double *ms, int *flags) {
+  constexpr int KS = WideGeom<NPW>::KS;
+  constexpr bool FROM_LOG = MODE == 1, TRATIO = MODE == 3;
+  extern __shared__ double emis_lds[];
+  double *ltab = emis_lds;
+  double *ltd = ltab + (size_t)(FROM_LOG ? 0 : em.lds_rows) * NP;
+  int *tinfo = (int *)(ltd + NPW);
+  const int K = em.K, KPW = em.KPW;
+  if (!FROM_LOG) {
+    // (em.ldsbase is this kernel's own assignment, launch_wide_emis: more tracks than the 32 KB the cooperative kernels
+    //  stage -- a row gathered from L2 in this lane mapping touches 16 cache lines per load; rows come from the table itself)
+    for (int k = 0; k < K; ++k) {
+      const int lb = em.ldsbase[k];
+      if (lb < 0) continue;
+      const double *src = em.tab + (size_t)em.rowbase[k] * NP;
+      for (int i = threadIdx.x; i < em.rowcnt[k] * NP; i += blockDim.x) ltab[(size_t)lb * NP + i] = src[i];
+    }
+    for (int i = threadIdx.x; i < NP; i += blockDim.x) ltab[(size_t)em.lds_zero * NP + i] = 0.0;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+      tinfo[k] = em.ldsbase[k];
+      tinfo[K + k] = em.rowcnt[k];
+      tinfo[2 * K + k] = em.rowbase[k];
+    }
   }
-  if (bad && lane == 0) atomicAdd(&flags[0], 1);
+  for (int j = threadIdx.x; j < NPW; j += blockDim.x) ltd[j] = (TRATIO && j < N) ? g_lt[(size_t)j * NP + j] : 0.0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int kq = lane >> 4, i16 = lane & 15;
+  const int L = lg.L;
+  const int SB = 16, nsb = (L + SB - 1) / SB;
+  const int64_t n_tiles = ((int64_t)lg.n_items + 15) / 16;
+  const bool eratio = em.ratios != nullptr;
+  int nbad = 0;
+  for (int64_t unit = (int64_t)blockIdx.x * 4 + wv; unit < n_tiles * nsb; unit += (int64_t)gridDim.x * 4) {
+    const int64_t tile = unit / nsb;
+    const int s_lo = (int)(unit - tile * nsb) * SB;
+    const int64_t item = tile * 16 + i16;
+    const bool valid = item < lg.n_items;
+    const int64_t itc = valid ? item : (int64_t)lg.n_items - 1;
+    const int id = lg.item_iv[itc];
+    const int64_t t0 = lg.item_t0[itc];
+    const int len = valid ? (int)min((int64_t)L, iv.len[id] - t0) : 0;
+    const int64_t g0 = iv.pos0[id] + t0;
+    const int s_hi = min(L, s_lo + SB);
+    // the observation words of the NEXT position are requested while this one is worked on (first four words: 16 tracks)
+    uint32_t wn[4] = {0u, 0u, 0u, 0u};
+    auto request = [&](int s) {
+      const uint32_t *orow = em.obs32 + (g0 + (s < len ? s : 0)) * KPW;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        if (d < KPW) wn[d] = orow[d];
+    };
+    if (!FROM_LOG) request(s_lo);
+    for (int s = s_lo; s < s_hi; ++s) {
+      const bool act = s < len;
+      const int sc = act ? s : 0;                                  // (loads from inside the item whatever happens)
+      double x[KS];
+      if (FROM_LOG) {
+        const double *src = BL + (g0 + sc) * TEHMM_WIDE_S + kq;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) x[k] = src[4 * k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) x[k] = 0.0;
+        uint32_t wc[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) wc[d] = wn[d];
+        if (s + 1 < s_hi) request(s + 1);
+        auto track = [&](int kk, uint32_t wd) {
+          const int sym = (int)((wd >> ((kk & 3) * 8)) & 0xffu);
+          const int lb = tinfo[kk];
+          const bool inr = sym < tinfo[K + kk];
+          // (a row is read up to state NPW - 1: beyond the model's NP padded states that is the next row or the slack
+          //  behind the table -- those states are dropped below)
+          // (two loops, not one pointer selected between LDS and global memory: that would be a FLAT pointer, and flat
+          //  loads of LDS addresses take the slow path -- the first version spent 78 % of its time waiting on them)
+          if (lb >= 0) {
+            const double *tr = ltab + (size_t)(inr ? lb + sym : em.lds_zero) * NP + kq;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) x[k] += tr[4 * k];
+          } else {
+            const double *tr = em.tab + (int64_t)(inr ? tinfo[2 * K + kk] + sym : em.zero_row) * NP + kq;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) x[k] += tr[4 * k];
+          }
+        };
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          if (4 * d < K) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (4 * d + u < K) track(4 * d + u, wc[d]);
+          }
+        }
+        for (int kk = 16; kk < K; ++kk) track(kk, em.obs32[(g0 + sc) * KPW + (kk >> 2)]);
+        double r = 1.0;
+        if (eratio || TRATIO) r = (TRATIO ? tratios : em.ratios)[g0 + sc];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          x[k] *= em.normalize;
+          if (eratio) x[k] *= r;
+          if (TRATIO && r > 1.) x[k] += ltd[kq + 4 * k] * (r - 1.);
+        }
+      }
+      double m = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < KS; ++k)
+        if (kq + 4 * k < N) m = fmax(m, x[k]);
+      m = item_max4(m);
+      const bool good = m > -1e20;
+      nbad += (act && !good) ? 1 : 0;
+      if (act) {
+        double *dst = E + wide_e_row<NPW>(item, L, s) + kq * 16;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) dst[(int64_t)k << 6] = (good && kq + 4 * k < N) ? exp_nonpos(x[k] - m) : 0.0;
+        if (kq == 0) ms[(tile * L + s) * 16 + i16] = good ? m : 0.0;
+      }
+    }
+  }
+  if (__any(nbad > 0) && lane == 0) atomicAdd(&flags[0], 1);
 }
 
 // A fragments of the workgroup: fwd: frag[rt][s][l] = A[4 s + (l >> 4)][16 rt + (l & 15)]  (new = A^T old)
@@ -148,7 +249,7 @@ void k_wide_fwd(IntervalTab iv, LaneGeom lg, int N, int NP, int Wu, const double
   const int64_t item = tile * 16 + (lane & 15);
   const bool valid = item < lg.n_items;
   const int id = valid ? lg.item_iv[item] : 0;
-  const int64_t t0 = valid ? lg.item_t0[item] : 0, T = iv.len[id], r0 = iv.out0[id] + t0;
+  const int64_t t0 = valid ? lg.item_t0[item] : 0, T = iv.len[id];
   const int L = lg.L;
   const int len = valid ? (int)min((int64_t)L, T - t0) : 0;
   // warm-up: Wu positions before the item, or -- where the interval starts within that reach -- everything from
@@ -163,16 +264,25 @@ void k_wide_fwd(IntervalTab iv, LaneGeom lg, int N, int NP, int Wu, const double
 #pragma unroll
     for (int k = 0; k < KS; ++k) dst[item * NPW + kq + 4 * k] = v[k];
   };
+  // Emission rows in the TILE layout (wide_e_row: the layout of the alpha' rows, one coalesced 512-byte load per k):
+  // position s of this lane's item is row s2 of item it2 -- another item of the same interval while s runs through the
+  // warm-up (it2, s2 advance with s)
+  const int64_t itc = valid ? item : (int64_t)lg.n_items - 1;
+  int64_t it2;
+  int s2;
+  wide_e_start(itc, L, -Wu, it2, s2);
+  const int64_t own0 = wide_e_row<NPW>(itc, L, 0) + kq * 16;
   for (int s = -Wu; s < L; ++s) {
     const bool act = valid && s < len && s >= -wu;
     if (s == 0 && valid && t0 > 0 && len > 0) vec_out(pre);
-    const double *er = E + (r0 + (act ? s : 0)) * (int64_t)NPW + kq;
-    const double msv = act ? ms[r0 + s] : 0.0;
+    const double *er = E + (act ? wide_e_row<NPW>(it2, L, s2) + kq * 16 : own0);
+    const double msv = act ? ms[((it2 >> 4) * L + s2) * 16 + (it2 & 15)] : 0.0;
+    if (++s2 == L) { s2 = 0; ++it2; }
     // the emission row is requested BEFORE the product (one wave per SIMD: nothing else hides its latency; round 3 read
     // it behind the product, twice)
     double ev[KS];
 #pragma unroll
-    for (int k = 0; k < KS; ++k) ev[k] = er[4 * k];
+    for (int k = 0; k < KS; ++k) ev[k] = er[(int64_t)k << 6];
     lane_d4 acc[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) acc[rt] = (lane_d4){0.0, 0.0, 0.0, 0.0};
@@ -247,10 +357,16 @@ void k_wide_bwd(IntervalTab iv, LaneGeom lg, int N, int NP, int Wu, const double
 #pragma unroll
     for (int k = 0; k < KS; ++k) dst[item * NPW + kq + 4 * k] = v[k];
   };
+  const int64_t itc = valid ? item : (int64_t)lg.n_items - 1;
+  int64_t it2;
+  int s2;
+  wide_e_start(itc, L, L + Wu - 1, it2, s2);                     // (emission rows in the tile layout: see k_wide_fwd)
+  const int64_t own0 = wide_e_row<NPW>(itc, L, 0) + kq * 16;
   for (int s = L + Wu - 1; s >= 0; --s) {
     const bool act = valid && len > 0 && s <= top;
     if (s == L - 1 && valid && !last) vec_out(pre);              // v = w_{t0 + L} as the warm-up left it
-    const double *er = E + (r0 + (act ? s : 0)) * (int64_t)NPW + kq;
+    const double *er = E + (act ? wide_e_row<NPW>(it2, L, s2) + kq * 16 : own0);
+    if (--s2 < 0) { s2 = L - 1; --it2; }
     const bool official = act && s < len;
     // emission and alpha' rows of this step are requested BEFORE the product (one wave per SIMD: nothing else hides
     // their latency); the alpha' row from a clamped position where the step has none
@@ -262,7 +378,7 @@ void k_wide_bwd(IntervalTab iv, LaneGeom lg, int N, int NP, int Wu, const double
     if (PRE_AL) {
 #pragma unroll
       for (int k = 0; k < KS; ++k) {
-        ev[k] = er[4 * k];
+        ev[k] = er[(int64_t)k << 6];
         av[k] = ar[(int64_t)k << 6];
       }
     }
@@ -307,7 +423,7 @@ void k_wide_bwd(IntervalTab iv, LaneGeom lg, int N, int NP, int Wu, const double
     }                                 // (the four lanes of an item take the branch together: item_sum4 is safe)
     if (act) {
 #pragma unroll
-      for (int k = 0; k < KS; ++k) v[k] = (PRE_AL ? ev[k] : er[4 * k]) * acc[k >> 2][k & 3];
+      for (int k = 0; k < KS; ++k) v[k] = (PRE_AL ? ev[k] : er[(int64_t)k << 6]) * acc[k >> 2][k & 3];
     }
   }
   if (valid && len > 0) vec_out(end);

@@ -7,7 +7,8 @@
 //     rounds 2-3 ran BaseHMM._do_estep over the array-level entry points, [T][N] fp64 lattices across PCIe five
 //     times per sequence;
 //   * segment ratios at any N <= 128 (fit on a segmented table, basehmm.py:510-512).  The passes of tehmm_wide.hip.h
-//     read their emission rows from HBM as exp(x - max), so the ratio is two more terms of x before the exponential:
+//     read their emission rows from HBM as exp(x - max), so the ratio is two more terms of x before the exponential
+//     (k_wide_emis_tile, modes 2 / 3):
 //         x_t[j] = r_t * normalize * sum_k logb_k[j]  +  [r_t > 1] lt[j][j] (r_t - 1)      (_hmm.pyx:131-140, 178-181)
 //     and the recurrences themselves do not change.  Rounds 2-3: ONE sequential chain per interval (k_fb_coop<TRATIO>).
 //
@@ -67,128 +68,6 @@ __global__ __launch_bounds__(256) void k_ratio_max(const double *__restrict__ r,
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
   if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
-}
-
-// ---- emission rows for fit: E [row][NPW] = exp(x - max), ms [row] = max, with the segment ratios applied the way
-// fit applies them (the emission ratio comes through em.ratios, the transition term is added here) -----------------
-template <bool TRATIO>
-__global__ __launch_bounds__(256) void k_wide_emis_fit(IntervalTab iv, EmisTab em, LaneGeom lg, int N, int NPW, int NP,
-                                                       const double *__restrict__ g_lt, const double *__restrict__ tratios,
-                                                       double *E, double *ms, int *flags) {
-  const int lane = threadIdx.x & 63;
-  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (item >= lg.n_items) return;
-  const int id = lg.item_iv[item];
-  const int64_t t0 = lg.item_t0[item], T = iv.len[id], p0 = iv.pos0[id], r0 = iv.out0[id];
-  const int len = (int)min((int64_t)lg.L, T - t0);
-  const double ltd0 = lane < N ? g_lt[(size_t)lane * NP + lane] : 0.0;
-  const double ltd1 = lane + 64 < N ? g_lt[(size_t)(lane + 64) * NP + lane + 64] : 0.0;
-  bool bad = false;
-  for (int s = 0; s < len; ++s) {
-    double x[2];
-    emis_log_wide(em, em.tab, p0 + t0 + s, lane, N, x);
-    if (TRATIO) {
-      const double r = tratios[p0 + t0 + s];
-      if (r > 1.) { x[0] += ltd0 * (r - 1.); x[1] += ltd1 * (r - 1.); }
-    }
-    const double m = row_max<2>(x, lane, N);
-    const bool good = m > -1e20;
-    bad = bad | !good;
-    double *dst = E + (r0 + t0 + s) * (int64_t)NPW;
-    if (lane < NPW) dst[lane] = (good && lane < N) ? exp_nonpos(x[0] - m) : 0.0;
-    if (lane + 64 < NPW) dst[lane + 64] = (good && lane + 64 < N) ? exp_nonpos(x[1] - m) : 0.0;
-    if (lane == 0) ms[r0 + t0 + s] = good ? m : 0.0;
-  }
-  if (bad && lane == 0) atomicAdd(&flags[0], 1);
-}
-
-// The same for at most 16 tracks (KPW <= 4 observation words per position), the form that is used: the kernel above
-// walks its item position by position behind a chain of dependent loads (observation word -> table row -> sum: 8 us
-// per position and wave, 2.0 of the 15.7 ms of the first version at 100 states).  Here the observation words (and
-// ratios) of SIXTEEN positions are one coalesced load, a position's symbols reach the table-row addresses through
-// v_readlane (they are wave-uniform), and the gathers of two positions are in flight together.
-template <bool TRATIO>
-__global__ __launch_bounds__(256) void k_wide_emis_fit16(IntervalTab iv, EmisTab em, LaneGeom lg, int N, int NPW, int NP,
-                                                         const double *__restrict__ g_lt, const double *__restrict__ tratios,
-                                                         double *E, double *ms, int *flags) {
-  // the rows of the small tracks are staged in LDS (em.ldsbase, as in the cooperative kernels): gathered from L2 every
-  // table row is 512 bytes per position and track whatever N is -- 23 GB per E-step over 5 Mb at 12 tracks, which is
-  // what the first version of this kernel spent its 3.2 ms on
-  extern __shared__ double emis_ltab[];
-  for (int i = threadIdx.x; i < em.lds_rows * NP; i += blockDim.x) emis_ltab[i] = em.ltab_src[i];
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (item >= lg.n_items) return;
-  const int id = lg.item_iv[item];
-  const int64_t t0 = lg.item_t0[item], T = iv.len[id], p0 = iv.pos0[id], r0 = iv.out0[id];
-  const int len = (int)min((int64_t)lg.L, T - t0);
-  const double ltd0 = lane < N ? g_lt[(size_t)lane * NP + lane] : 0.0;
-  const double ltd1 = lane + 64 < N ? g_lt[(size_t)(lane + 64) * NP + lane + 64] : 0.0;
-  const int KPW = em.KPW, K = em.K;
-  const int lp = lane / KPW, ld = lane - lp * KPW;                   // this lane's (position of the block, word)
-  const int j0 = lane < N ? lane : 0, j1 = lane + 64 < N ? lane + 64 : 0;
-  const bool two = N > 64;
-  const bool eratio = em.ratios != nullptr;
-  // track k's table info in lane k, read back with v_readlane (from the kernel arguments every use is a scalar load
-  // the gathers wait for: 15 per position)
-  const int lk = min(lane, K - 1);
-  const int ti_cnt = em.rowcnt[lk], ti_lb = em.ldsbase[lk], ti_rb = em.rowbase[lk];
-  bool bad = false;
-  for (int s0 = 0; s0 < len; s0 += 16) {
-    const int nb = min(16, len - s0);
-    const int64_t g0 = p0 + t0 + s0;
-    const uint32_t ow = lp < nb ? em.obs32[(g0 + lp) * KPW + ld] : 0u;
-    double rv = 1.0;
-    if (TRATIO || eratio) rv = (lane < nb) ? (TRATIO ? tratios : em.ratios)[g0 + lane] : 1.0;
-    for (int p = 0; p < nb; p += 2) {
-      // two positions per iteration (the second one clamped at the block's end and dropped): their gathers are issued
-      // together
-      const int pq[2] = {p, min(p + 1, nb - 1)};
-      double x0[2] = {0.0, 0.0}, x1[2] = {0.0, 0.0};
-      for (int k0 = 0; k0 < K; k0 += 4) {
-        double v0[2][4], v1[2][4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const uint32_t wd = (uint32_t)__builtin_amdgcn_readlane((int)ow, pq[h] * KPW + (k0 >> 2));
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int k = min(k0 + u, K - 1);
-            const int sym = (int)((wd >> (u * 8)) & 0xffu);
-            const bool inr = sym < __builtin_amdgcn_readlane(ti_cnt, k);
-            const int lb = __builtin_amdgcn_readlane(ti_lb, k);
-            const double *tr = lb >= 0 ? emis_ltab + (inr ? lb + sym : em.lds_zero) * NP
-                                       : em.tab + (int64_t)(inr ? __builtin_amdgcn_readlane(ti_rb, k) + sym : em.zero_row) * NP;
-            v0[h][u] = tr[j0];
-            v1[h][u] = two ? tr[j1] : 0.0;
-          }
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (k0 + u < K) { x0[h] += v0[h][u]; x1[h] += v1[h][u]; }
-      }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        if (h == 1 && p + 1 >= nb) break;
-        double xa = x0[h] * em.normalize, xb = x1[h] * em.normalize;
-        const double r = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rv), pq[h]),
-                                          __builtin_amdgcn_readlane(__double2loint(rv), pq[h]));
-        if (eratio) { xa *= r; xb *= r; }
-        if (TRATIO && r > 1.) { xa += ltd0 * (r - 1.); xb += ltd1 * (r - 1.); }
-        double x[2] = {xa, xb};
-        const double m = row_max<2>(x, lane, N);
-        const bool good = m > -1e20;
-        bad = bad | !good;
-        double *dst = E + (r0 + t0 + s0 + pq[h]) * (int64_t)NPW;
-        if (lane < NPW) dst[lane] = (good && lane < N) ? exp_nonpos(xa - m) : 0.0;
-        if (lane + 64 < NPW) dst[lane + 64] = (good && lane + 64 < N) ? exp_nonpos(xb - m) : 0.0;
-        if (lane == 0) ms[r0 + t0 + s0 + pq[h]] = good ? m : 0.0;
-      }
-    }
-  }
-  if (bad && lane == 0) atomicAdd(&flags[0], 1);
 }
 
 template <int NPW>
