@@ -115,7 +115,8 @@ int tehmm_model_destroy(tehmm_model_t *model);
 /* Observations of n_intervals TrackTables, concatenated: interval i is rows
  * offsets[i] .. offsets[i+1]-1 of obs [total][K] (uint8, IntegerTrackTable.data, track.py:555) and
  * of segRatios [total] (may be NULL).  obs_on_device != 0: obs/segRatios are device pointers on
- * the current device (the data stays where it is and is repacked by a kernel). */
+ * the current device (the data stays where it is and is repacked by a kernel on the batch's own stream, after
+ * the work queued on the default stream; a producer on any other stream must have finished). */
 int tehmm_batch_create(int n_intervals, const int64_t *offsets, int K, const uint8_t *obs,
                        const double *segRatios, int obs_on_device, tehmm_batch_t **out);
 int tehmm_batch_destroy(tehmm_batch_t *batch);

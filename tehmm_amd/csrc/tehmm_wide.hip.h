@@ -53,6 +53,10 @@ __device__ __forceinline__ void wide_e_start(int64_t item, int L, int s, int64_t
   it2 = item + d;
   s2 = s - d * L;
 }
+// row stride (doubles) of k_wide_emis_tile's redistribution buffer: the smallest value >= NPW that is 4 mod 32, so that the
+// 64 lanes (item, kq) of a read-back hit 32 different 8-byte banks twice
+__host__ __device__ constexpr int wide_emis_tstride(int NPW) { return NPW <= 36 ? 36 : NPW <= 68 ? 68 : NPW <= 100 ? 100 : 132; }
+
 // The emission kernel in the lane mapping of the passes: lane = (item of a 16-item tile, state quarter kq), a lane
 // holds the states kq + 4 k of ITS item's position.  Per track the symbol is per-lane data (one byte extract), the
 // table row one base address, and the row's KS values KS loads at immediate offsets + KS additions: ~80 instructions
@@ -61,7 +65,8 @@ __device__ __forceinline__ void wide_e_start(int64_t item, int L, int s, int64_t
 //   the same evaluation has written;  MODE 2: fit without ratios;  MODE 3: fit with segment ratios (emission rows
 //   scaled by r_t, emission.py:195-196; + lt[j][j] (r_t - 1) where r_t > 1, _hmm.pyx:131-140).
 // grid = persistent workgroups over units of (tile, 16 positions); block = 256 (one unit per wave at a time).
-// LDS: ltab [lds_rows][NP] | ltd [NPW] | tinfo [3][K].  flags[0] counts units with a row no state can emit.
+// LDS: tbuf [4 waves][8][TS] | ltab [lds_rows][NP] | ltd [NPW] | tinfo [3][K].  flags[0] counts units with a row no state
+// can emit.
 template <int NPW, int MODE>
 __global__ __launch_bounds__(256) void k_wide_emis_tile(IntervalTab iv, EmisTab em, LaneGeom lg, int N, int NP,
                                                         const double *__restrict__ g_lt, const double *__restrict__ tratios,
@@ -69,7 +74,9 @@ __global__ __launch_bounds__(256) void k_wide_emis_tile(IntervalTab iv, EmisTab 
   constexpr int KS = WideGeom<NPW>::KS;
   constexpr bool FROM_LOG = MODE == 1, TRATIO = MODE == 3;
   extern __shared__ double emis_lds[];
-  double *ltab = emis_lds;
+  constexpr int TS = wide_emis_tstride(NPW);          // row stride of the per-wave redistribution buffer (== 4 mod 32)
+  double *tbuf = emis_lds + (size_t)(threadIdx.x >> 6) * (8 * TS);      // [4 waves][8 items][TS]
+  double *ltab = emis_lds + (FROM_LOG ? 0 : 4 * 8 * TS);
   double *ltd = ltab + (size_t)(FROM_LOG ? 0 : em.lds_rows) * NP;
   int *tinfo = (int *)(ltd + NPW);
   const int K = em.K, KPW = em.KPW;
@@ -146,9 +153,38 @@ __global__ __launch_bounds__(256) void k_wide_emis_tile(IntervalTab iv, EmisTab 
 #pragma unroll
             for (int k = 0; k < KS; ++k) x[k] += tr[4 * k];
           } else {
-            const double *tr = em.tab + (int64_t)(inr ? tinfo[2 * K + kk] + sym : em.zero_row) * NP + kq;
+            // A track whose rows stay in global memory (the 250-bin tracks).  Gathered in this lane mapping -- 32 bytes
+            // per item and load -- a row costs 16 cache-line reads per load, 28 line reads per position and track at 112
+            // states: 1.1e8 per 2 Mb, 7 TB/s of L2 traffic, 1.9 ms with the vector pipe 7 % busy.  Instead the WAVE reads
+            // the row of one item at a time, coalesced (two 512-byte loads), into a per-wave LDS buffer [8 items][TS]
+            // (TS == 4 mod 32: the read-back below is conflict-free), and every lane takes its states from there.
+            const int rb = tinfo[2 * K + kk];
+            const int rown = inr ? rb + sym : em.zero_row;
 #pragma unroll
-            for (int k = 0; k < KS; ++k) x[k] += tr[4 * k];
+            for (int half = 0; half < 2; ++half) {
+              double r0v[8], r1v[8];
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                const int ri = __builtin_amdgcn_readlane(rown, half * 8 + i);      // lane i16 (kq = 0) holds item i16's row
+                const double *row = em.tab + (int64_t)ri * NP;
+                r0v[i] = row[min(lane, NP - 1)];
+                r1v[i] = NPW > 64 ? row[min(lane + 64, NP - 1)] : 0.0;
+              }
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                if (lane < TS) tbuf[i * TS + lane] = r0v[i];
+                if (NPW > 64 && lane + 64 < TS) tbuf[i * TS + lane + 64] = r1v[i];
+              }
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              if ((i16 >> 3) == half) {
+                const double *tr = tbuf + (i16 & 7) * TS + kq;
+#pragma unroll
+                for (int k = 0; k < KS; ++k) x[k] += tr[4 * k];
+              }
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+            }
           }
         };
 #pragma unroll

@@ -7,7 +7,7 @@
 set -o pipefail
 tag=${1:-r03}
 shift
-parts=${*:-stats traffic estep esteptraffic strong stage pmc}
+parts=${*:-stats traffic estep esteptraffic wide strong stage pmc}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 mkdir -p "$out"
@@ -52,6 +52,14 @@ if has pmc; then
   # SQ counters of the headline kernels (three --pmc passes each; kernels serialised by the profiler)
   STAGES=both timeout -k 10 900 bash "$root/tools/pmc.sh" "${tag}" "k_vit_lane3|k_emis_gain|k_fused_fwd|k_fused_bwd|k_vit_fix|k_tb_" tools/stage_bench.py 100 > "$out/${tag}_pmc.log" 2>&1 || exit 11
   echo "pmc done"
+fi
+if has wide; then
+  # E-step on the item-parallel passes (100 states with ratios 2 Mb, 35 states with ratios 5 Mb) and config 5
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_prof_wide" -o "${tag}_wide" -- \
+    python3 "$root/tools/wide_estep_bench.py" wide ratios --no-verify > "$out/${tag}_wide_estep_under_rocprof.txt" 2> "$out/${tag}_prof_wide.err" || exit 12
+  timeout -k 10 300 python3 "$root/tools/wide_estep_bench.py" wide ratios > "$out/${tag}_wide_estep.txt" 2> "$out/${tag}_wide_estep.err" || exit 13
+  timeout -k 10 120 python3 "$root/tools/config5_bench.py" > "$out/${tag}_config5.txt" 2>&1 || exit 14
+  echo "wide done"
 fi
 if has strong; then
   timeout -k 10 400 $B --scaling strong --no-extra > "$out/${tag}_bench_strong_1gpu.json" 2> "$out/${tag}_bench_strong.err" || exit 7
