@@ -3846,24 +3846,33 @@ static int launch_wide_estep_reduce(tehmm_batch *b, const tehmm_model *m, const 
   HIPCHK(w.part_xi.ensure((size_t)gxm * G::TPW * NPW * NPW));
   const int nrt = w.h_rows.n_rt;
   const int64_t slot_rows = (int64_t)nrt * 16 * NPW * 8;
-  const int gxr = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_units, 1024), std::max<int64_t>(256, ((int64_t)128 << 20) / slot_rows)));
-  HIPCHK(w.part_rows.ensure((size_t)gxr * nrt * 16 * NPW));
+  // gamma product: four units per workgroup at a time (one per wave), up to three row tiles per wave; partial buffer <= 128 MB
+  const int rtw = std::min(nrt, NPW <= 64 ? 4 : 3);      // (every group of row tiles reads the gamma rows once more)
+  const int gxr = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((n_units + 3) / 4, 256), std::max<int64_t>(64, ((int64_t)32 << 20) / slot_rows)));
+  HIPCHK(w.part_rows.ensure((size_t)gxr * 4 * nrt * 16 * NPW));
   // the products are independent: the gamma product and the LDS histograms run on their own streams next to the xi
   // product (TEHMM_WIDE_ESTEP_SERIAL=1: one after the other, for profiling)
   const bool serial = std::getenv("TEHMM_WIDE_ESTEP_SERIAL") != nullptr;
   hipStream_t sB = serial ? st : b->sB, sV = serial ? st : b->sV;
   (void)hipEventRecord(b->evX[0], st);
   (void)hipStreamWaitEvent(sB, b->evX[0], 0);
-  if (ratio)
-    hipLaunchKernelGGL((k_wide_estep_rows<NPW, true>), dim3(gxr, (nrt + 3) / 4), dim3(256), 0, sB, iv, lg,
-                       (const WideRows *)w.d_rows.p, b->KP, (const uint8_t *)b->obs.p, (const double *)b->ratios.p,
-                       (const float *)w.GAM.p, w.part_rows.p, SQ);
-  else
-    hipLaunchKernelGGL((k_wide_estep_rows<NPW, false>), dim3(gxr, (nrt + 3) / 4), dim3(256), 0, sB, iv, lg,
-                       (const WideRows *)w.d_rows.p, b->KP, (const uint8_t *)b->obs.p, (const double *)nullptr,
-                       (const float *)w.GAM.p, w.part_rows.p, SQ);
+  {
+    const dim3 gr(gxr, (nrt + rtw - 1) / rtw);
+#define ROWS(R_, W_)                                                                                                    \
+    hipLaunchKernelGGL((k_wide_estep_rows<NPW, R_, W_>), gr, dim3(256), 0, sB, iv, lg, (const WideRows *)w.d_rows.p, b->KP, \
+                       (const uint8_t *)b->obs.p, (const double *)(R_ ? b->ratios.p : nullptr), (const float *)w.GAM.p,  \
+                       w.part_rows.p, SQ)
+    if constexpr (NPW <= 64) {
+      if (rtw == 4) { if (ratio) ROWS(true, 4); else ROWS(false, 4); }
+    }
+    if (rtw < 4) {
+      if (ratio) { if (rtw == 1) ROWS(true, 1); else if (rtw == 2) ROWS(true, 2); else ROWS(true, 3); }
+      else { if (rtw == 1) ROWS(false, 1); else if (rtw == 2) ROWS(false, 2); else ROWS(false, 3); }
+    }
+#undef ROWS
+  }
   hipLaunchKernelGGL(k_wide_fold_rows, dim3((nrt * 16 * m->N + 255) / 256), dim3(256), 0, sB, (const double *)w.part_rows.p,
-                     gxr, m->N, NPW, m->NP, (const WideRows *)w.d_rows.p, gstat, gstart, gD);
+                     gxr * 4, m->N, NPW, m->NP, (const WideRows *)w.d_rows.p, gstat, gstart, gD);
   (void)hipEventRecord(b->evX[1], sB);
   if (w.h_lds.n_trk > 0) {
     // tracks with many symbols: fixed-point histograms privatised in LDS, on a third stream

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_wide_estep_xi(IntervalTab iv, LaneGeom 
       for (int tb = 0; tb < RT; ++tb) {
         w[tb][0] = (double)xw[tb].x; w[tb][1] = (double)xw[tb].y; w[tb][2] = (double)xw[tb].z; w[tb][3] = (double)xw[tb].w;
       }
-      if (s + 1 < nsmax) request(s + 1);
+      request(min(s + 1, nsmax - 1));            // (unconditional: count-static waits, see k_wide_estep_rows)
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -170,10 +170,11 @@ __global__ __launch_bounds__(256) void k_wide_estep_xi(IntervalTab iv, LaneGeom 
 
 // ------------------------------------------------------------------------------------------
 // Everything linear in gamma: out[row][j] += sum over (item, position) a[row][item] gamma[j][item].
-// grid (x = persistent workgroups over the item tiles, y = groups of four row tiles), block = 256: wave w owns row
-// tile 4 y + w.  part: [gridDim.x slots][n_rt * 16 rows][NPW].
+// grid (x = persistent workgroups over the units, y = groups of RTW row tiles), block = 256: every wave takes its own
+// unit and the RTW row tiles of its group (the first version gave a wave ONE row tile: 7 row loads and 28 conversions
+// per 28 matrix instructions, 1.0 ms per 2 Mb for 0.27 ms of matrix pipe).  part: [4 gridDim.x slots][n_rt * 16 rows][NPW].
 // ------------------------------------------------------------------------------------------
-template <int NPW, bool RATIO>
+template <int NPW, bool RATIO, int RTW>
 __global__ __launch_bounds__(256) void k_wide_estep_rows(IntervalTab iv, LaneGeom lg, const WideRows *__restrict__ wr, int KP,
                                                          const uint8_t *__restrict__ obs, const double *__restrict__ ratios,
                                                          const float *__restrict__ GAM, double *part, int SQ) {
@@ -181,18 +182,25 @@ __global__ __launch_bounds__(256) void k_wide_estep_rows(IntervalTab iv, LaneGeo
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int m = lane & 15, k4 = lane >> 4;
   const int nrt = wr->n_rt;
-  const int rt = blockIdx.y * 4 + wv;
-  if (rt >= nrt) return;                                   // (no barrier in this kernel)
-  const int inf = wr->info[rt * 16 + m];
-  const int kind = inf < 0 ? 3 : inf == TEHMM_WIDE_ROW_START ? 1 : inf == TEHMM_WIDE_ROW_DIAG ? 2 : 0;
-  const int col = kind == 0 ? (inf & 255) : 0, rsym = kind == 0 ? (inf >> 8) : -1;
-  lane_d4 acc[RT];
+  // this wave's RTW row tiles (rows beyond the table: padding rows, a = 0)
+  int kind[RTW], col[RTW], rsym[RTW];
 #pragma unroll
-  for (int tb = 0; tb < RT; ++tb) acc[tb] = (lane_d4){0.0, 0.0, 0.0, 0.0};
+  for (int r = 0; r < RTW; ++r) {
+    const int rt = blockIdx.y * RTW + r;
+    const int inf = rt < nrt ? wr->info[rt * 16 + m] : -1;
+    kind[r] = inf < 0 ? 3 : inf == TEHMM_WIDE_ROW_START ? 1 : inf == TEHMM_WIDE_ROW_DIAG ? 2 : 0;
+    col[r] = kind[r] == 0 ? (inf & 255) : 0;
+    rsym[r] = kind[r] == 0 ? (inf >> 8) : -1;
+  }
+  lane_d4 acc[RTW][RT];
+#pragma unroll
+  for (int r = 0; r < RTW; ++r)
+#pragma unroll
+    for (int tb = 0; tb < RT; ++tb) acc[r][tb] = (lane_d4){0.0, 0.0, 0.0, 0.0};
   const int64_t n_tiles = ((int64_t)lg.n_items + 15) / 16;
   const float4 *gam4 = (const float4 *)GAM;
   const int LQ = lg.L / SQ;
-  for (int64_t unit = blockIdx.x; unit < n_tiles * SQ; unit += gridDim.x) {
+  for (int64_t unit = (int64_t)blockIdx.x * 4 + wv; unit < n_tiles * SQ; unit += (int64_t)gridDim.x * 4) {
     const int64_t tile = unit / SQ;
     const int s_lo = (int)(unit - tile * SQ) * LQ;
     // the lane's four items 4 k4 + kk: observation rows, ratios, lengths
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(256) void k_wide_estep_rows(IntervalTab iv, LaneGeo
       const int64_t t0 = lg.item_t0[itc];
       nsk[kk] = valid ? (int)min((int64_t)lg.L, iv.len[id] - t0) : 0;
       rp[kk] = iv.pos0[id] + t0;
-      oo[kk] = rp[kk] * KP + col;
+      oo[kk] = rp[kk] * KP;
       t0k[kk] = t0;
       nsmax = max(nsmax, nsk[kk]);
     }
@@ -216,10 +224,10 @@ __global__ __launch_bounds__(256) void k_wide_estep_rows(IntervalTab iv, LaneGeo
     nsmax = min(__builtin_amdgcn_readfirstlane(nsmax), s_lo + LQ);
     if (nsmax <= s_lo) continue;
     const int64_t b4 = tile * lg.L * (int64_t)(NPW * 4) + m * 4 + k4;
-    // TWO steps are on their way at any time (buffers 0 / 1): with one, the matrix instructions of a step (0.75 us)
-    // were all that covered the latency of the next step's rows -- 4 us per step at two waves per SIMD
+    // TWO steps are on their way at any time (buffers 0 / 1): the matrix instructions of one step do not cover the
+    // latency of the next step's rows
     float4 xg[2][RT];
-    int sy[2][4];
+    int sy[2][RTW][4];
     double rr[2][4];
     auto request = [&](int s, auto bsel) {
       constexpr int B = decltype(bsel)::value;
@@ -228,45 +236,62 @@ __global__ __launch_bounds__(256) void k_wide_estep_rows(IntervalTab iv, LaneGeo
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const int sc = max(0, min(s, nsk[kk] - 1));           // unconditional loads from inside the item
-        sy[B][kk] = (int)obs[oo[kk] + (int64_t)sc * KP];
+#pragma unroll
+        for (int r = 0; r < RTW; ++r) sy[B][r][kk] = (int)obs[oo[kk] + (int64_t)sc * KP + col[r]];
         rr[B][kk] = RATIO ? ratios[rp[kk] + sc] : 1.0;
       }
     };
     auto step = [&](int s, auto bsel) {
       constexpr int B = decltype(bsel)::value;
-      double a[4], g[RT][4];
+      double a[RTW][4], g[RT][4];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const double r = rr[B][kk];
-        double v = (sy[B][kk] == rsym) ? r : 0.0;                                     // kind 0 (rsym = -1 otherwise)
-        v = kind == 1 ? ((s == 0 && t0k[kk] == 0) ? 1.0 : 0.0) : v;
-        v = kind == 2 ? ((RATIO && r > 1. && t0k[kk] + s > 0) ? r - 1. : 0.0) : v;
-        a[kk] = s < nsk[kk] ? v : 0.0;
+        const bool live = s < min(nsk[kk], nsmax);
+        const double vstart = (s == 0 && t0k[kk] == 0) ? 1.0 : 0.0;
+        const double vdiag = (RATIO && r > 1. && t0k[kk] + s > 0) ? r - 1. : 0.0;
+#pragma unroll
+        for (int q = 0; q < RTW; ++q) {
+          double v = (sy[B][q][kk] == rsym[q]) ? r : 0.0;                             // kind 0 (rsym = -1 otherwise)
+          v = kind[q] == 1 ? vstart : v;
+          v = kind[q] == 2 ? vdiag : v;
+          a[q][kk] = live ? v : 0.0;
+        }
       }
 #pragma unroll
       for (int tb = 0; tb < RT; ++tb) {
         g[tb][0] = (double)xg[B][tb].x; g[tb][1] = (double)xg[B][tb].y; g[tb][2] = (double)xg[B][tb].z; g[tb][3] = (double)xg[B][tb].w;
       }
-      if (s + 2 < nsmax) request(s + 2, bsel);
+      // (every step issues the same loads -- the last ones a second time --: behind a branch that may or may not have
+      //  issued them the compiler's wait for the OLDER buffer becomes vmcnt(0), and the latency of every step shows)
+      request(min(s + 2, nsmax - 1), bsel);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-        for (int tb = 0; tb < RT; ++tb) acc[tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], g[tb][kk], acc[tb], 0, 0, 0);
+        for (int q = 0; q < RTW; ++q)
+#pragma unroll
+          for (int tb = 0; tb < RT; ++tb) acc[q][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][kk], g[tb][kk], acc[q][tb], 0, 0, 0);
     };
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
     request(s_lo, B0{});
-    if (s_lo + 1 < nsmax) request(s_lo + 1, B1{});
+    request(min(s_lo + 1, nsmax - 1), B1{});
     for (int s = s_lo; s < nsmax; s += 2) {
       step(s, B0{});
-      if (s + 1 < nsmax) step(s + 1, B1{});
+      step(s + 1, B1{});                         // (s + 1 == nsmax: nothing is live, zeros are added)
     }
   }
-  double *slot = part + (size_t)blockIdx.x * (size_t)(nrt * 16) * NPW;
+  double *slot = part + ((size_t)blockIdx.x * 4 + wv) * (size_t)(nrt * 16) * NPW;
 #pragma unroll
-  for (int tb = 0; tb < RT; ++tb)
+  for (int r = 0; r < RTW; ++r) {
+    const int rt = blockIdx.y * RTW + r;
+    if (rt < nrt) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) slot[(size_t)(rt * 16 + 4 * q + k4) * NPW + 16 * tb + m] = acc[tb][q];
+      for (int tb = 0; tb < RT; ++tb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) slot[(size_t)(rt * 16 + 4 * q + k4) * NPW + 16 * tb + m] = acc[r][tb][q];
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -325,7 +350,7 @@ __global__ __launch_bounds__(512) void k_wide_estep_hist_lds(IntervalTab iv, Lan
       for (int i = 0; i < HQ; ++i) gc[i] = gn[i];
       const int sym = syn;
       const double f = rn * fscale;
-      if (s + 1 < nsmax) request(s + 1);
+      request(min(s + 1, nsmax - 1));
       // (a symbol beyond the track's last one lands in the reference's padding cells, which emission.maximize never
       //  reads: not booked)
       if (s < ns && sym < rows) {

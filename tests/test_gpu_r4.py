@@ -398,35 +398,52 @@ def test_device_em_100_states_matches_host_loop(monkeypatch):
     assert_allclose(a._log_startprob, b._log_startprob, rtol=1e-6, atol=1e-9)
 
 
-def test_batch_from_device_arrays_waits_for_the_default_stream():
+_DEVICE_ARRAYS_SCRIPT = r"""
+import sys
+import numpy as np
+import torch
+from tehmm_amd import synth
+from tehmm_amd.engine import HipBatch, HipModel
+model = synth.make_model(9, (3, 5, 4), (), seed=2)
+lens = [300_000, 200_000]
+offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+total = int(offs[-1])
+obs_h = synth.sample_obs(model, total, seed=4)
+hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, symbols_per_track=model.symbols_per_track)
+dev = torch.device("cuda", 0)
+for rep in range(3):
+    g = torch.Generator(device=dev)
+    g.manual_seed(5 + rep)
+    obs_d = torch.from_numpy(obs_h).to(dev)
+    x = torch.rand(total, generator=g, device=dev, dtype=torch.float64)
+    for _ in range(20):                                # keep the default stream busy right up to the create call
+        x = torch.sqrt(x * x + 1e-3)
+    r_d = (torch.clamp(1 + torch.floor(torch.log1p(-x * 0.999) / np.log(1 - 1 / 20.0)), max=100.0) / 20.0).contiguous()
+    hb = HipBatch(obs_d.data_ptr(), offs, ratios=r_d.data_ptr(), device_ptrs=True, K=3)
+    res = hm.eval(hb, viterbi=True, posterior=False, use_ratios=True)
+    p_dev, lp_dev = hb.paths(), res["viterbi_logprob"].copy()
+    hb.close()
+    hb2 = HipBatch(obs_h, offs, r_d.cpu().numpy())
+    res2 = hm.eval(hb2, viterbi=True, posterior=False, use_ratios=True)
+    if not (np.array_equal(p_dev, hb2.paths()) and np.array_equal(lp_dev, res2["viterbi_logprob"])):
+        print("MISMATCH in repetition", rep)
+        sys.exit(1)
+    hb2.close()
+hm.close()
+print("OK")
+"""
+
+
+def test_batch_from_device_arrays_waits_for_the_default_stream(tmp_path):
     """tehmm_batch_create with device pointers repacks on the batch's own non-blocking stream: arrays the caller has just
     queued work for on the default stream (torch tensors filled a moment ago) must be complete when they are read --
-    the same decode as from host copies of the same arrays."""
-    import torch
-    from tehmm_amd import synth
-    from tehmm_amd.engine import HipBatch, HipModel
-    model = synth.make_model(9, (3, 5, 4), (), seed=2)
-    lens = [300_000, 200_000]
-    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-    total = int(offs[-1])
-    obs_h = synth.sample_obs(model, total, seed=4)
-    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, symbols_per_track=model.symbols_per_track)
-    dev = torch.device("cuda", 0)
-    for rep in range(3):
-        g = torch.Generator(device=dev)
-        g.manual_seed(5 + rep)
-        obs_d = torch.from_numpy(obs_h).to(dev)
-        x = torch.rand(total, generator=g, device=dev, dtype=torch.float64)
-        for _ in range(20):                                # keep the default stream busy right up to the create call
-            x = torch.sqrt(x * x + 1e-3)
-        r_d = (torch.clamp(1 + torch.floor(torch.log1p(-x * 0.999) / np.log(1 - 1 / 20.0)), max=100.0) / 20.0).contiguous()
-        hb = HipBatch(obs_d.data_ptr(), offs, ratios=r_d.data_ptr(), device_ptrs=True, K=3)
-        res = hm.eval(hb, viterbi=True, posterior=False, use_ratios=True)
-        p_dev, lp_dev = hb.paths(), res["viterbi_logprob"].copy()
-        hb.close()
-        hb2 = HipBatch(obs_h, offs, r_d.cpu().numpy())
-        res2 = hm.eval(hb2, viterbi=True, posterior=False, use_ratios=True)
-        assert_array_equal(p_dev, hb2.paths())
-        assert_array_equal(lp_dev, res2["viterbi_logprob"])
-        hb2.close()
-    hm.close()
+    the same decode as from host copies of the same arrays.  (Own process: torch's GPU context.)"""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "device_arrays.py"
+    script.write_text(_DEVICE_ARRAYS_SCRIPT)
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + env.get("PYTHONPATH", "")
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
