@@ -839,7 +839,10 @@ __global__ __launch_bounds__(512) void k_vit_wide_spec(IntervalTab iv, VitChunks
       const double qao0 = 2.0 * za0 - qa0, qao1 = 2.0 * za1 - qa1, qbo0 = 2.0 * zb0 - qb0, qbo1 = 2.0 * zb1 - qb1;
       const int ph = pb[h];
       double x0 = -INFINITY, x1 = -INFINITY;
-      auto cand = [&](double sv, int f) {
+      // (the addends selected below are captured BY VALUE: selected through by-reference captures the compiler kept
+      //  pointers to them in scratch and loaded the chosen one through a flat pointer -- 328 bytes of scratch per lane)
+      auto cand = [&, bo0, bo1, bq0, bq1, qa0, qa1, qao0, qao1, qb0, qb1, qbo0, qbo1, lt00q, rg, ph, pbq0, pbq1,
+                   tb0, tb1, tza0, tza1, tzb0, tzb1](double sv, int f) {
         double c0 = sv + tq[f * TEHMM_WIDE_S + lane], c1 = sv + tq[f * TEHMM_WIDE_S + lane + 64];
         for (int k = 0; k < n_tt; ++k)
           if ((ttab[k] & 255) == f) {

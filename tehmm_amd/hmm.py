@@ -441,11 +441,14 @@ class MultitrackHmm(BaseHMM):
         and the M-step see global values and take identical decisions everywhere.  A rank whose shard is
         empty still takes part, with zero statistics."""
         from . import dist as tdist
+        from ._lib import TeHmmHipError
         from .engine import DeviceStats, HipBatch
         if self.algorithm not in ("viterbi", "map"):
             self._algorithm = "viterbi"
         world, rank = tdist.world_rank()
         n_seq = len(tables)
+        lengths_given = lengths is not None
+        fallback = False
         if lengths is None:
             lengths = [len(t) for t in tables]
         # every rank must hold the same GLOBAL list (or its lengths): a caller that passes per-rank shards would train
@@ -479,9 +482,21 @@ class MultitrackHmm(BaseHMM):
                 stats.zero()
                 loc_idx, loc_lp = [], []
                 for has_r, idx, hb in batches:
-                    hm.estep_device(hb, has_r, stats)
+                    try:
+                        hm.estep_device(hb, has_r, stats)
+                    except TeHmmHipError as e:
+                        # 64..128 states: a batch the item-parallel passes do not take (a row no state can emit, fewer
+                        # than 1024 rows, links that never verify).  Before anything has been learned -- and with no
+                        # other rank waiting in a collective -- the reference's own loop over the array-level entry
+                        # points takes the whole fit
+                        if e.code == -3 and i == 0 and world == 1 and lengths_given is False:
+                            fallback = True
+                            break
+                        raise
                     loc_idx.extend(idx)
                     loc_lp.extend(hb.interval_logprobs())
+                if fallback:
+                    break
                 seq_lp = tdist.gather_interval_scalars(loc_idx, loc_lp, n_seq)
                 if self.maxProb is True:
                     self._pull_params(hm)
@@ -509,6 +524,14 @@ class MultitrackHmm(BaseHMM):
                 hb.close()
             self._pull_params(hm)
             stats.close()
+        if fallback:
+            keep = self.init_params
+            self.init_params = ""                      # (_init has run; the parameters are the ones it left)
+            self.current_iteration = 1
+            try:
+                return BaseHMM.fit(self, tables)
+            finally:
+                self.init_params = keep
         self.validate()
         return self
 

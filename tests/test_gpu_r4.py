@@ -154,7 +154,7 @@ def test_estep_statistics_bit_reproducible(monkeypatch, N, symbols, gauss):
         monkeypatch.delenv(k, raising=False)
     model = (synth.make_model(N, synth.CONFIG4_SYMBOLS, synth.CONFIG4_GAUSSIAN, seed=12) if symbols is None
              else synth.make_model(N, symbols, gauss, seed=12 + N))
-    lens = [100_000] * 6 + [33_333, 1, 2_500]
+    lens = [100_000] * 3 + [33_333, 1, 2_500]
     offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     obs = synth.sample_obs(model, int(offs[-1]), seed=5, missing=0.02)
     K, _, S = model.log_probs.shape
@@ -362,6 +362,44 @@ def test_wide_estep_falls_back(monkeypatch):
         hm.close()
 
 
+def test_device_em_falls_back_to_the_host_loop_at_70_states(monkeypatch):
+    """MultitrackHmm.fit at 70 states on a table with a row no state can emit: the item-parallel passes refuse it
+    (TEHMM_ERR_UNSUPPORTED), _fit_device hands the whole fit to the reference's loop over the array-level entry points
+    -- the same parameters as with the device path switched off."""
+    from tehmm_amd import synth
+    from tehmm_amd.emission import IndependentMultinomialEmissionModel
+    from tehmm_amd.hmm import MultitrackHmm
+    for k in KNOBS + ("TEHMM_ESTEP_WIDE", "TEHMM_DEVICE_EM"):
+        monkeypatch.delenv(k, raising=False)
+    N, sym = 70, [3, 5, 4]
+    init = synth.make_model(N, tuple(sym), (), seed=4)
+    lp3 = init.log_probs.copy()
+    lp3[1, :, 2] = -np.inf                       # symbol 2 of track 1: no state can emit it
+    lp3[1, :, 1:6] -= np.log(np.exp(lp3[1, :, 1:6]).sum(axis=1))[:, None]     # (still a distribution: validate())
+    seqs = [synth.sample_obs(init, T, seed=60 + i) for i, T in enumerate([1500, 900])]
+    seqs[0][:, 1] = np.where(seqs[0][:, 1] == 2, 1, seqs[0][:, 1])
+    seqs[1][:, 1] = np.where(seqs[1][:, 1] == 2, 1, seqs[1][:, 1])
+    seqs[1][0, 1] = 2                            # a LEADING impossible row: the reference skips it (quirk, _emission.pyx:73-80)
+
+    def fresh():
+        em = IndependentMultinomialEmissionModel(N, sym)
+        em.logProbs = lp3.copy()
+        h = MultitrackHmm(em, n_iter=2, thresh=0.0, fixStart=False)
+        h.transmat_ = init.transmat.copy()
+        h.init_params = ""
+        return h
+
+    a = fresh()
+    assert a._can_fit_on_device(seqs)
+    a.fit(seqs)
+    assert a.init_params == ""
+    monkeypatch.setenv("TEHMM_DEVICE_EM", "0")
+    b = fresh()
+    b.fit(seqs)
+    assert_allclose(a._log_transmat, b._log_transmat, rtol=1e-9, atol=1e-12)
+    assert_allclose(a.emissionModel.logProbs, b.emissionModel.logProbs, rtol=1e-9, atol=1e-12)
+
+
 @pytest.mark.timeout(900)
 def test_device_em_100_states_matches_host_loop(monkeypatch):
     """MultitrackHmm.fit at 100 states: device-resident EM (_fit_device over tehmm_estep_batch_device on the
@@ -417,15 +455,15 @@ for rep in range(3):
     obs_d = torch.from_numpy(obs_h).to(dev)
     x = torch.rand(total, generator=g, device=dev, dtype=torch.float64)
     for _ in range(20):                                # keep the default stream busy right up to the create call
-        x = torch.sqrt(x * x + 1e-3)
-    r_d = (torch.clamp(1 + torch.floor(torch.log1p(-x * 0.999) / np.log(1 - 1 / 20.0)), max=100.0) / 20.0).contiguous()
+        x = torch.clamp(torch.sqrt(x * x), 0.0, 0.999)
+    r_d = (torch.clamp(1 + torch.floor(torch.log1p(-x) / np.log(1 - 1 / 20.0)), max=100.0) / 20.0).contiguous()
     hb = HipBatch(obs_d.data_ptr(), offs, ratios=r_d.data_ptr(), device_ptrs=True, K=3)
     res = hm.eval(hb, viterbi=True, posterior=False, use_ratios=True)
     p_dev, lp_dev = hb.paths(), res["viterbi_logprob"].copy()
     hb.close()
     hb2 = HipBatch(obs_h, offs, r_d.cpu().numpy())
     res2 = hm.eval(hb2, viterbi=True, posterior=False, use_ratios=True)
-    if not (np.array_equal(p_dev, hb2.paths()) and np.array_equal(lp_dev, res2["viterbi_logprob"])):
+    if not (np.isfinite(lp_dev).all() and np.array_equal(p_dev, hb2.paths()) and np.array_equal(lp_dev, res2["viterbi_logprob"])):
         print("MISMATCH in repetition", rep)
         sys.exit(1)
     hb2.close()
