@@ -33,7 +33,7 @@ extern "C" {
 #define TEHMM_ERR_UNSUPPORTED (-3) /* shape outside what the kernels support (see tehmm_max_states) */
 
 /* ---- library / device ---------------------------------------------------------------------- */
-int tehmm_abi_version(void);                 /* bumps when a signature changes or is added (2) */
+int tehmm_abi_version(void);                 /* bumps when a signature changes or is added (3) */
 const char *tehmm_last_error(void);          /* thread-local message of the last failing call */
 int tehmm_device_count(int *count);          /* hipGetDeviceCount */
 int tehmm_set_device(int device);            /* hipSetDevice; one process per GPU calls this once */
@@ -119,6 +119,14 @@ int tehmm_model_destroy(tehmm_model_t *model);
  * the work queued on the default stream; a producer on any other stream must have finished). */
 int tehmm_batch_create(int n_intervals, const int64_t *offsets, int K, const uint8_t *obs,
                        const double *segRatios, int obs_on_device, tehmm_batch_t **out);
+/* The same from the other two observation types of the reference (IntegerTrackTable with uint16 / int32 data:
+ * _fastAllLogProbsU16 / 32, _fastAccumulateStatsU16 / 32, _emission.pyx:82-144, 192-234), host arrays only.  The fused
+ * kernels keep one byte per track and position: a symbol outside 0..255 returns TEHMM_ERR_UNSUPPORTED (such tables go
+ * through the array-level entry points, which take all three types). */
+int tehmm_batch_create_u16(int n_intervals, const int64_t *offsets, int K, const uint16_t *obs,
+                           const double *segRatios, tehmm_batch_t **out);
+int tehmm_batch_create_i32(int n_intervals, const int64_t *offsets, int K, const int32_t *obs,
+                           const double *segRatios, tehmm_batch_t **out);
 int tehmm_batch_destroy(tehmm_batch_t *batch);
 int64_t tehmm_batch_total(const tehmm_batch_t *batch);
 /* Forgets what earlier evaluations derived from the batch's observations for a model (the table-row index

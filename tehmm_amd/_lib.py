@@ -60,6 +60,8 @@ SIGNATURES = {
                                    ctypes.POINTER(vp)]),
     "tehmm_model_destroy": (c_int, [vp]),
     "tehmm_batch_create": (c_int, [c_int, i64p, c_int, vp, vp, c_int, ctypes.POINTER(vp)]),
+    "tehmm_batch_create_u16": (c_int, [c_int, i64p, c_int, vp, vp, ctypes.POINTER(vp)]),
+    "tehmm_batch_create_i32": (c_int, [c_int, i64p, c_int, vp, vp, ctypes.POINTER(vp)]),
     "tehmm_batch_destroy": (c_int, [vp]),
     "tehmm_batch_total": (c_i64, [vp]),
     "tehmm_batch_reset_cache": (c_int, [vp]),

@@ -457,7 +457,7 @@ struct tehmm_batch {
 
 // All tehmm_* functions below are declared extern "C" in include/tehmm_hip.h.
 
-int tehmm_abi_version(void) { return 2; }
+int tehmm_abi_version(void) { return 3; }
 const char *tehmm_last_error(void) { return g_err.c_str(); }
 int tehmm_max_states(void) { return kMaxStates; }
 
@@ -956,6 +956,33 @@ int tehmm_batch_create(int n, const int64_t *offsets, int K, const uint8_t *obs,
   }
   *out = b;
   return TEHMM_OK;
+}
+
+// uint16 / int32 observation tables on the fused path: narrowed to the byte rows the kernels keep (a symbol beyond 255
+// cannot be: TEHMM_ERR_UNSUPPORTED, the array-level entry points take such tables)
+template <typename T>
+static int batch_create_narrow(int n, const int64_t *offsets, int K, const T *obs, const double *segRatios, tehmm_batch_t **out,
+                               const char *who) {
+  if (!out) return fail(TEHMM_ERR_ARG, std::string(who) + ": out is NULL");
+  *out = nullptr;
+  if (n < 0 || K <= 0 || !offsets || (n > 0 && offsets[n] > 0 && !obs)) return fail(TEHMM_ERR_ARG, std::string(who) + ": bad argument");
+  const int64_t total = n > 0 ? offsets[n] : 0;
+  if (total < 0) return fail(TEHMM_ERR_ARG, std::string(who) + ": bad offsets");
+  std::vector<uint8_t> bytes((size_t)total * K);
+  for (size_t i = 0; i < bytes.size(); ++i) {
+    const long long v = (long long)obs[i];
+    if (v < 0 || v > 255)
+      return fail(TEHMM_ERR_UNSUPPORTED, std::string(who) + ": symbol outside 0..255 (the fused kernels keep one byte per track and "
+                                                            "position: use the array-level entry points)");
+    bytes[i] = (uint8_t)v;
+  }
+  return tehmm_batch_create(n, offsets, K, bytes.data(), segRatios, 0, out);
+}
+int tehmm_batch_create_u16(int n, const int64_t *offsets, int K, const uint16_t *obs, const double *segRatios, tehmm_batch_t **out) {
+  return batch_create_narrow(n, offsets, K, obs, segRatios, out, "tehmm_batch_create_u16");
+}
+int tehmm_batch_create_i32(int n, const int64_t *offsets, int K, const int32_t *obs, const double *segRatios, tehmm_batch_t **out) {
+  return batch_create_narrow(n, offsets, K, obs, segRatios, out, "tehmm_batch_create_i32");
 }
 
 int tehmm_batch_destroy(tehmm_batch_t *b) {

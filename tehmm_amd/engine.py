@@ -173,7 +173,11 @@ class HipBatch(object):
             o = ctypes.c_void_p(int(obs))
             r = ctypes.c_void_p(int(ratios)) if ratios else None
         else:
-            obs = np.ascontiguousarray(obs, dtype=np.uint8)
+            # uint8 rows as they are; uint16 / int32 tables (the reference's other two IntegerTrackTable types) through
+            # tehmm_batch_create_u16 / _i32, which refuse symbols beyond 255
+            obs = np.asarray(obs)
+            kind = {np.dtype(np.uint16): "u16", np.dtype(np.int32): "i32"}.get(obs.dtype)
+            obs = np.ascontiguousarray(obs, dtype=obs.dtype if kind else np.uint8)
             assert obs.ndim == 2 and obs.shape[0] == offsets[-1]
             self.K = obs.shape[1]
             o = obs.ctypes.data_as(ctypes.c_void_p)
@@ -181,6 +185,13 @@ class HipBatch(object):
             if rr is not None:
                 assert rr.shape[0] == offsets[-1]
             r = None if rr is None else rr.ctypes.data_as(ctypes.c_void_p)
+            if kind:
+                fn = getattr(_lib.load(), "tehmm_batch_create_" + kind)
+                _lib.check(fn(self.n, ptr(offsets, i64p), self.K, o, r, ctypes.byref(h)), "tehmm_batch_create_" + kind)
+                self._h = h
+                self.N = None
+                self.total = int(offsets[-1])
+                return
         _lib.check(_lib.load().tehmm_batch_create(self.n, ptr(offsets, i64p), self.K, o, r,
                                                   1 if device_ptrs else 0, ctypes.byref(h)),
                    "tehmm_batch_create")

@@ -201,7 +201,12 @@ class MultitrackHmm(BaseHMM):
             return False
         for t in tables:
             a = t.getNumPyArray() if isinstance(t, TrackTable) else t
-            if not (isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.ndim == 2):
+            if not (isinstance(a, np.ndarray) and a.ndim == 2):
+                return False
+            if a.dtype == np.uint8:
+                continue
+            # uint16 / int32 tables (track.py:555: the type follows the largest symbol) whose symbols fit a byte
+            if a.dtype not in (np.uint16, np.int32) or (a.size and (a.max() > 255 or a.min() < 0)):
                 return False
         return True
 

@@ -272,6 +272,7 @@ def _seg_ratios(total, seed, mean=4.0):
     (35, (3, 5, 4, 30, 250), (4,), True),                 # segment ratios below 64 states: 48 padded states here
     (5, (3, 5, 4), (), True),                             # one state tile
     (60, (4, 250, 30), (1,), True),                       # 64 padded states, a 250-bin track in the gamma product
+    (20, (2,) * 20, (), True),                            # 32 padded states; 20 tracks: observation words beyond the fourth
 ])
 def test_wide_estep_vs_oracle(monkeypatch, N, symbols, gauss, use_ratios):
     """tehmm_estep_batch on the item-parallel passes (k_wide_emis_fit, k_wide_fwd, k_wide_bwd<ESTEP>, k_wide_estep_xi,
@@ -485,3 +486,42 @@ def test_batch_from_device_arrays_waits_for_the_default_stream(tmp_path):
     env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + env.get("PYTHONPATH", "")
     p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_uint16_and_int32_tables_on_the_fused_path():
+    """The reference's other two IntegerTrackTable types (_emission.pyx:82-144, 192-234): a uint16 / int32 table whose
+    symbols fit a byte runs on the fused path (tehmm_batch_create_u16 / _i32) with the results of its uint8 copy, decode
+    and E-step; a symbol beyond 255 is refused with TEHMM_ERR_UNSUPPORTED (MultitrackHmm then stays on the array-level
+    entry points, which take all three types)."""
+    from tehmm_amd import _lib, synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    from tehmm_amd.hmm import MultitrackHmm
+    from tehmm_amd.emission import IndependentMultinomialEmissionModel
+    model = synth.make_model(7, (3, 5, 4), (), seed=8)
+    lens = [30_000, 1, 12_345]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    obs = synth.sample_obs(model, int(offs[-1]), seed=9, missing=0.02)
+    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, symbols_per_track=model.symbols_per_track)
+    K, N, S = model.log_probs.shape
+    ref = None
+    for dt in (np.uint8, np.uint16, np.int32):
+        hb = HipBatch(obs.astype(dt), offs)
+        res = hm.eval(hb, viterbi=True, posterior=True)
+        start, trans, st = np.zeros(N), np.zeros((N, N)), np.zeros((K, N, S))
+        lp = hm.estep(hb, False, start, trans, st)
+        got = (hb.paths(), res["viterbi_logprob"].copy(), hb.posteriors(N), lp, trans, st)
+        hb.close()
+        if ref is None:
+            ref = got
+        else:
+            for a, b in zip(got, ref):
+                assert_array_equal(np.asarray(a), np.asarray(b))
+    bad = obs.astype(np.uint16)
+    bad[17, 1] = 300
+    with pytest.raises(_lib.TeHmmHipError) as ei:
+        HipBatch(bad, offs)
+    assert ei.value.code == -3
+    hm.close()
+    em = IndependentMultinomialEmissionModel(7, [3, 5, 4])
+    h = MultitrackHmm(em)
+    assert h._can_fuse([obs.astype(np.int32)]) and not h._can_fuse([bad]) and not h._can_fuse([obs.astype(np.int64)])
