@@ -525,3 +525,41 @@ def test_uint16_and_int32_tables_on_the_fused_path():
     em = IndependentMultinomialEmissionModel(7, [3, 5, 4])
     h = MultitrackHmm(em)
     assert h._can_fuse([obs.astype(np.int32)]) and not h._can_fuse([bad]) and not h._can_fuse([obs.astype(np.int64)])
+
+
+@pytest.mark.timeout(900)
+def test_config5_one_megabase_vs_oracle(monkeypatch):
+    """BASELINE configs[4] at bench size: 100 states, 10 tracks, segment ratios, 1 Mb in 10 intervals of 100 kb, decode
+    and score_samples in ONE evaluation (item-parallel posterior with the tile-layout emission rows taken from the log
+    rows of the exact Viterbi, chunk-parallel exact Viterbi with both tie hypotheses): state paths and scores bit for
+    bit, posteriors at 1e-6 (observed error asserted at 3e-7), forward log-likelihoods at 1e-9 against the oracle
+    (oracle.eval_batch over all host threads: the reference's teHmmEval flow)."""
+    import os
+    from tehmm_amd import synth
+    from tehmm_amd.engine import HipBatch, HipModel
+    from oracle import oracle
+    for k in KNOBS + ("TEHMM_WIDE_VIT", "TEHMM_WIDE_CP", "TEHMM_WIDE_TOL"):
+        monkeypatch.delenv(k, raising=False)
+    model = synth.make_model(100, synth.CONFIG2_SYMBOLS, synth.CONFIG2_GAUSSIAN, seed=0)
+    lens = [100_000] * 10
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    T = int(offs[-1])
+    obs = _noisy_obs(model, T, seed=33)
+    ratios = np.ascontiguousarray(synth.random_ratios(T, seed=6))
+    hm = HipModel(model.log_transmat, model.log_startprob, model.log_probs, symbols_per_track=model.symbols_per_track)
+    hb = HipBatch(obs, offs, ratios)
+    res = hm.eval(hb, viterbi=True, posterior=True, use_ratios=True)
+    tm = hb.timing()
+    paths, post = hb.paths(), hb.posteriors(100)
+    hb.close()
+    hm.close()
+    assert tm.get("count:viterbi_chunk_jumps", 0) > 0 and "count:wide_chunk_parallel_warmup" in tm      # both chunk-parallel paths ran
+    p_o, vlp_o, flp_o, post_o = oracle.eval_batch(obs, offs, model.log_probs, model.log_startprob, model.log_transmat, 1.0,
+                                                  ratios, want_post=True, n_threads=max(1, min(16, os.cpu_count() or 1)))
+    assert_array_equal(paths, p_o)
+    assert_array_equal(res["viterbi_logprob"], vlp_o)
+    assert_allclose(res["forward_logprob"], flp_o, rtol=1e-9)
+    worst = float(np.max(np.abs(post - post_o) / post_o))
+    print("config 5, 1 Mb: posterior max rel err %.3g" % worst)
+    assert_allclose(post, post_o, rtol=1e-6, atol=0)
+    assert worst <= 3e-7
