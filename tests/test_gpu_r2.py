@@ -307,15 +307,23 @@ def test_config2_full_size_vs_oracle():
     rowsum_dev = hb.posterior_masksum(np.ones(35))
     assert_allclose(rowsum_dev, 1.0, rtol=1e-9)
     hb.close()
+    # the oracle's two sequential passes over 10 Mb side by side (ctypes calls release the GIL): 35 s instead of 50
+    import threading
+    out = {}
+
+    def _forward():
+        frame = oracle.emission(obs, model.log_probs, 1.0, None)
+        fwd = oracle.forward(model.log_startprob, model.log_transmat, frame)
+        out["flp"] = oracle.logsumexp(fwd[-1])
+
+    th = threading.Thread(target=_forward)
+    th.start()
     lp_o, path_o = oracle.decode(obs, model.log_probs, model.log_startprob, model.log_transmat)
+    th.join()
     assert_array_equal(paths, path_o)
     assert res["viterbi_logprob"][0] == lp_o
     del path_o, paths
-    frame = oracle.emission(obs, model.log_probs, 1.0, None)
-    fwd = oracle.forward(model.log_startprob, model.log_transmat, frame)
-    del frame
-    flp = oracle.logsumexp(fwd[-1])
-    assert_allclose(res["forward_logprob"][0], flp, rtol=RTOL)
+    assert_allclose(res["forward_logprob"][0], out["flp"], rtol=RTOL)
 
 
 @pytest.mark.parametrize("variant", ["sticky", "sparse"])
