@@ -50,7 +50,7 @@ def build(force=False, verbose=False, dev_nt=None):
     if not force and not needs_build(flags):
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
-           "-std=c++17", "-Wall", "-Wno-unused-function", "-o", LIB] + SOURCES
+           "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-lambda-capture", "-o", LIB] + SOURCES
     if flags:
         cmd[1:1] = flags.split()
     if verbose:
