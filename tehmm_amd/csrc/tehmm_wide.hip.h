@@ -10,12 +10,12 @@
 //   * the N x N transition matrix lives in LDS as matrix-core A fragments [row tile][k step][lane] (100 KB at 112
 //     padded states, 131 KB at 128): one conflict-free ds_read_b64 per matrix instruction, shared by the four waves
 //     of a workgroup -- LDS bandwidth is 4 % of the matrix time;
-//   * the emission rows are not fused: k_wide_emis (lane = state pair, coalesced table rows, reference summation
-//     order) leaves exp(row - max) and the max per position in HBM, both passes read them back (2.7 KB per position,
-//     HBM time << matrix time at this N);
+//   * the emission rows are not fused: k_wide_emis_tile (round 4: in the lane mapping of the passes, see below) leaves
+//     exp(row - max) and the max per position in HBM in the layout of the alpha' rows, both passes read them back
+//     (2.7 KB per position, HBM time << matrix time at this N);
 //   * there is no sequential chain: an item either starts exactly (the first item of an interval forward, the last
 //     one backward) or warms up over Wu positions from a uniform vector, and k_wide_links CHECKS every link (Hilbert
-//     distance <= TEHMM_FB_TOL between the vector an item arrives with and the one its neighbour left).  One failed
+//     distance <= 1e-8 (round 4; 1e-10 before) between the vector an item arrives with and the one its neighbour left).  One failed
 //     link -- or an emission row no state can emit, whose semantics (quirk Q9, NaN lattices) belong to the sequential
 //     kernels -- and the host retries with twice the warm-up, then falls back to the sequential kernels.
 // Padded state counts: 80, 96, 112, 128 (row tiles of 16); pads carry zero probability.

@@ -275,7 +275,7 @@ def _seg_ratios(total, seed, mean=4.0):
     (20, (2,) * 20, (), True),                            # 32 padded states; 20 tracks: observation words beyond the fourth
 ])
 def test_wide_estep_vs_oracle(monkeypatch, N, symbols, gauss, use_ratios):
-    """tehmm_estep_batch on the item-parallel passes (k_wide_emis_fit, k_wide_fwd, k_wide_bwd<ESTEP>, k_wide_estep_xi,
+    """tehmm_estep_batch on the item-parallel passes (k_wide_emis_tile, k_wide_fwd, k_wide_bwd<ESTEP>, k_wide_estep_xi,
     k_wide_estep_rows) against the oracle's per-sequence E-step (basehmm.py:504-523, hmm.py:545-574,
     _hmm.pyx:62-117 with the diagonal ratio term, _emission.pyx:183-190 with ratio-weighted posteriors) on ragged
     intervals: one-row, sub-item and multi-item intervals, tails shorter than an item.  Statistics at 1e-6 (written
