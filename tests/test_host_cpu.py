@@ -27,6 +27,31 @@ def test_library_exports_every_declared_symbol():
     assert lib.tehmm_max_states() == 128
 
 
+def test_fused_path_takes_the_three_observation_types_of_the_reference():
+    """IntegerTrackTable data is uint8, uint16 or int32 (track.py:555, the type follows the largest symbol): the fused
+    path takes all three while the symbols fit a byte (tehmm_batch_create / _u16 / _i32), anything else stays on the
+    array-level entry points.  The narrowing entry points refuse a symbol beyond 255 before any device call."""
+    from tehmm_amd import _lib
+    from tehmm_amd.emission import IndependentMultinomialEmissionModel
+    from tehmm_amd.hmm import MultitrackHmm
+    h = MultitrackHmm(IndependentMultinomialEmissionModel(4, [3, 5]))
+    a = np.array([[1, 2], [3, 5], [0, 1]])
+    assert h._can_fuse([a.astype(np.uint8)]) and h._can_fuse([a.astype(np.uint16)]) and h._can_fuse([a.astype(np.int32)])
+    assert not h._can_fuse([a.astype(np.int64)]) and not h._can_fuse([a.astype(np.float64)])
+    big = a.astype(np.uint16)
+    big[1, 0] = 256
+    neg = a.astype(np.int32)
+    neg[0, 0] = -1
+    assert not h._can_fuse([big]) and not h._can_fuse([neg]) and not h._can_fuse([a.astype(np.uint8), big])
+    lib = _lib.load()
+    assert lib.tehmm_abi_version() >= 3
+    offs = np.asarray([0, 3], dtype=np.int64)
+    out = ctypes.c_void_p()
+    for fn, arr in ((lib.tehmm_batch_create_u16, big), (lib.tehmm_batch_create_i32, neg)):
+        rc = fn(1, offs.ctypes.data_as(_lib.i64p), 2, arr.ctypes.data_as(ctypes.c_void_p), None, ctypes.byref(out))
+        assert rc == -3 and b"outside 0..255" in lib.tehmm_last_error()         # TEHMM_ERR_UNSUPPORTED, no device touched
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     """Without a device the array-level entry points must fail with an error code (and the Python
     wrappers raise); nothing silently computes on the CPU."""
